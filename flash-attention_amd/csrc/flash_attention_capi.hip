@@ -1,0 +1,239 @@
+// Host side of libflash_attention.so: validation, launch configuration, timing
+// and the two host<->device convenience paths.  Interface and behaviour follow
+// the reference's flash_attention_tensor_cores/wrapper.cu (cited per function
+// in include/flash_attention.h); the implementation shares nothing with it.
+#include "../../include/flash_attention.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "fa_fwd_kernel.hpp"
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+    std::snprintf(g_last_error, sizeof(g_last_error), fmt, detail);
+    return code;
+}
+
+#define FA_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            std::snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s", #call,    \
+                          hipGetErrorString(_e));                                         \
+            return FA_ERR_RUNTIME;                                                        \
+        }                                                                                 \
+    } while (0)
+
+// Workgroup size: 8 waves (256 query rows) halve the K/V traffic per query row and are the
+// default; 4 waves are used when 8 would not divide the rows or would leave CUs idle.
+int pick_waves(int bh, int lq) {
+    if (const char* e = std::getenv("FA_NWAVES")) {
+        const int n = std::atoi(e);
+        if (n == 4 || n == 8) return n;
+    }
+    if (lq % 256 != 0) return 4;
+    const long blocks8 = (long)bh * (lq / 256);
+    return blocks8 >= 512 ? 8 : 4;
+}
+
+int launch(const fa::FwdParams& base, hipStream_t stream) {
+    fa::FwdParams p = base;
+    const int nw = pick_waves(p.bh, p.lq);
+    const int qb_rows = nw * fa::kRowsPerWave;
+    p.q_blocks = (p.lq + qb_rows - 1) / qb_rows;
+    const long grid = (long)p.bh * p.q_blocks;
+    if (grid <= 0 || grid > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
+    if (nw == 8)
+        hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL(fa::fa_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+
+int validate(int B, int H, int L, int D, int tile) {
+    if (tile != 64) return fail(FA_ERR_TILE, "run_tensor_flash_attention: tile must be 64%s");
+    if (D != fa::kHeadDim) return fail(FA_ERR_HEAD_DIM, "run_tensor_flash_attention: D must be 128%s");
+    if (L <= 0 || L % tile != 0)
+        return fail(FA_ERR_SEQLEN, "run_tensor_flash_attention: L must be divisible by tile%s");
+    if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "run_tensor_flash_attention: B and H must be positive%s");
+    if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "run_tensor_flash_attention: B*H too large%s");
+    return FA_OK;
+}
+
+__global__ void init_half_kernel(fa::half_t* ptr, size_t n, unsigned long long seed) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) {
+        const float v = fmodf((float)((idx * 16807ULL + seed) & 0xFFFFULL), 1024.f) / 1024.f - 0.5f;
+        ptr[idx] = (fa::half_t)v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fa_last_error(void) { return g_last_error; }
+
+const char* fa_version(void) { return "flash_attention gfx950 0.1"; }
+
+int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
+               int D, int tile, void* stream_, float* elapsed_ms) {
+    g_last_error[0] = 0;
+    if (int rc = validate(B, H, L, D, tile)) return rc;
+    if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "run_tensor_flash_attention: null tensor pointer%s");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    fa::FwdParams p{};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.bh = B * H;
+    p.lq = L;
+    p.lk = L;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.flags = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (elapsed_ms) {
+        FA_HIP(hipEventCreate(&ev0));
+        FA_HIP(hipEventCreate(&ev1));
+        FA_HIP(hipEventRecord(ev0, stream));
+    }
+    int rc = launch(p, stream);
+    if (elapsed_ms) {
+        if (rc == FA_OK) {
+            hipError_t e = hipEventRecord(ev1, stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ev1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+            if (e != hipSuccess) {
+                std::snprintf(g_last_error, sizeof(g_last_error), "event timing failed: %s", hipGetErrorString(e));
+                rc = FA_ERR_RUNTIME;
+            } else {
+                *elapsed_ms = ms;
+            }
+        }
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    return rc;
+}
+
+int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                         int H, int L, int D, int tile, void* stream_, float* elapsed_ms) {
+    g_last_error[0] = 0;
+    if (int rc = validate(B, H, L, D, tile)) return rc;
+    if (!hQ || !hK || !hV || !hO) return fail(FA_ERR_POINTER, "run_tensor_flash_attention_host_half: null pointer%s");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t bytes = (size_t)B * H * L * D * sizeof(uint16_t);
+    uint16_t* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = FA_OK;
+    for (int i = 0; i < 4 && rc == FA_OK; ++i)
+        if (hipMalloc(reinterpret_cast<void**>(&d[i]), bytes) != hipSuccess)
+            rc = fail(FA_ERR_RUNTIME, "hipMalloc failed in run_tensor_flash_attention_host_half%s");
+    auto step = [&](hipError_t e, const char* what) {
+        if (rc == FA_OK && e != hipSuccess) {
+            std::snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s", what, hipGetErrorString(e));
+            rc = FA_ERR_RUNTIME;
+        }
+    };
+    if (rc == FA_OK) {
+        step(hipMemcpyAsync(d[0], hQ, bytes, hipMemcpyHostToDevice, stream), "copy Q");
+        step(hipMemcpyAsync(d[1], hK, bytes, hipMemcpyHostToDevice, stream), "copy K");
+        step(hipMemcpyAsync(d[2], hV, bytes, hipMemcpyHostToDevice, stream), "copy V");
+        step(hipStreamSynchronize(stream), "stream sync");
+    }
+    if (rc == FA_OK) rc = fa_forward(d[0], d[1], d[2], d[3], B, H, L, D, tile, stream_, elapsed_ms);
+    if (rc == FA_OK) {
+        step(hipMemcpyAsync(hO, d[3], bytes, hipMemcpyDeviceToHost, stream), "copy O");
+        step(hipStreamSynchronize(stream), "stream sync");
+    }
+    for (int i = 0; i < 4; ++i)
+        if (d[i]) (void)hipFree(d[i]);
+    return rc;
+}
+
+int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
+                     float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int first, int last,
+                     void* stream_) {
+    g_last_error[0] = 0;
+    if (D != fa::kHeadDim) return fail(FA_ERR_HEAD_DIM, "fa_forward_block: D must be 128%s");
+    if (Lq <= 0 || Lk <= 0 || Lq % 64 != 0 || Lk % 64 != 0)
+        return fail(FA_ERR_SEQLEN, "fa_forward_block: Lq and Lk must be positive multiples of 64%s");
+    if (BH <= 0 || BH > 0x7fffffff / 64) return fail(FA_ERR_SHAPE, "fa_forward_block: bad BH%s");
+    if (!dQ || !dK || !dV) return fail(FA_ERR_POINTER, "fa_forward_block: null tensor pointer%s");
+    if (last && !dO) return fail(FA_ERR_POINTER, "fa_forward_block: last step needs dO%s");
+    if ((!first || !last) && (!o_acc || !row_max || !row_sum))
+        return fail(FA_ERR_POINTER, "fa_forward_block: state pointers required%s");
+
+    fa::FwdParams p{};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.o_acc = o_acc;
+    p.row_max = row_max;
+    p.row_sum = row_sum;
+    p.bh = BH;
+    p.lq = Lq;
+    p.lk = Lk;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.flags = (first ? 0 : fa::kFlagLoadState) | (last ? 0 : fa::kFlagStoreState);
+    return launch(p, static_cast<hipStream_t>(stream_));
+}
+
+int fa_init_half(uint16_t* dptr, size_t n, unsigned long long seed, void* stream_) {
+    g_last_error[0] = 0;
+    if (!dptr) return fail(FA_ERR_POINTER, "fa_init_half: null pointer%s");
+    if (n == 0) return FA_OK;
+    const int threads = 256;
+    size_t blocks = (n + threads - 1) / threads;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(init_half_kernel, dim3((unsigned)blocks), dim3(threads), 0, static_cast<hipStream_t>(stream_),
+                       reinterpret_cast<fa::half_t*>(dptr), n, seed);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+
+int fa_device_info(int* compute_units, int* clock_khz, double* fp16_dense_peak_flops) {
+    g_last_error[0] = 0;
+    int dev = 0;
+    FA_HIP(hipGetDevice(&dev));
+    int cus = 0, khz = 0;
+    FA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    FA_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev));
+    if (compute_units) *compute_units = cus;
+    if (clock_khz) *clock_khz = khz;
+    if (fp16_dense_peak_flops) *fp16_dense_peak_flops = (double)cus * 4.0 * 1024.0 * (double)khz * 1e3;
+    return FA_OK;
+}
+
+// The two drop-in symbols keep the reference's error convention (wrapper.cu:25,56,60,201):
+// failures surface as std::runtime_error.
+void run_tensor_flash_attention(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO,
+                                int B, int H, int L, int D, int tile, void* stream, float* elapsed_ms) {
+    if (fa_forward(dQ, dK, dV, dO, B, H, L, D, tile, stream, elapsed_ms) != FA_OK)
+        throw std::runtime_error(g_last_error);
+}
+
+void run_tensor_flash_attention_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV,
+                                          uint16_t* hO, int B, int H, int L, int D, int tile, void* stream,
+                                          float* elapsed_ms) {
+    if (fa_forward_host_half(hQ, hK, hV, hO, B, H, L, D, tile, stream, elapsed_ms) != FA_OK)
+        throw std::runtime_error(g_last_error);
+}
+
+}  // extern "C"

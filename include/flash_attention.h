@@ -1,0 +1,117 @@
+/*
+ * C ABI of libflash_attention.so (MI355X / gfx950 build).
+ *
+ * The first two functions are the drop-in boundary: same names, parameter order
+ * and widths as the reference's
+ *   flash_attention_tensor_cores/wrapper.cuh:8-19   run_tensor_flash_attention
+ *   flash_attention_tensor_cores/wrapper.cuh:21-32  run_tensor_flash_attention_host_half
+ * (`__half*` is a 16-bit pointer, `cudaStream_t` a pointer-sized handle; here
+ * they are spelled uint16_t* and void* so that the header needs no GPU
+ * toolkit).  The ctypes view used by benchmarks/compare_impls.py:34-40,
+ * [POINTER(c_uint16)]*4 + [c_int]*5 + [c_void_p, POINTER(c_float)], restype
+ * None, binds to them unchanged.
+ *
+ * Tensors are contiguous row-major [B][H][L][D] IEEE binary16
+ * (element (((b*H+h)*L+i)*D+d), testing.cu:49-51).  D must be 128,
+ * `tile` must be 64 (kept for compatibility: it is the key-tile cadence of the
+ * online softmax, wrapper.cu:53-57), L must be a multiple of 64
+ * (wrapper.cu:59-61).  Unlike the reference (wrapper.cu:89-185), every B, H and
+ * every such L is accepted and honoured at run time.
+ *
+ * The fa_* functions are additions of this library (status-returning twins,
+ * the blockwise entry point used by the sequence-parallel ring, the benchmark
+ * driver's input generator, device facts for the roofline).
+ */
+#ifndef FLASH_ATTENTION_H
+#define FLASH_ATTENTION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#define FA_DEFAULT(x) = x
+extern "C" {
+#else
+#define FA_DEFAULT(x)
+#endif
+
+/* ---------------------------------------------------------------------------
+ * Drop-in entry points
+ * ------------------------------------------------------------------------- */
+
+/* Replaces wrapper.cu:39-203.  Device pointers.  Asynchronous on `stream` when
+ * elapsed_ms is NULL; when non-NULL the call brackets the kernel with events,
+ * waits for it and stores the kernel-only milliseconds (wrapper.cu:79-85,
+ * 188-196).  Errors (bad tile / L / D, launch failure) are raised the way the
+ * reference raises them: a std::runtime_error thrown through the C boundary
+ * (wrapper.cu:56,60,201), i.e. std::terminate under a C or ctypes caller. */
+void run_tensor_flash_attention(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO,
+                                int B, int H, int L, int D, int tile,
+                                void* stream FA_DEFAULT(0), float* elapsed_ms FA_DEFAULT(0));
+
+/* Replaces wrapper.cu:9-35.  Host pointers: allocates four device buffers,
+ * copies Q,K,V host->device on `stream`, runs the kernel, copies O back, waits,
+ * frees.  *elapsed_ms is kernel-only time, copies excluded. */
+void run_tensor_flash_attention_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV,
+                                          uint16_t* hO, int B, int H, int L, int D, int tile,
+                                          void* stream FA_DEFAULT(0), float* elapsed_ms FA_DEFAULT(0));
+
+/* ---------------------------------------------------------------------------
+ * Additions (no counterpart in the reference unless cited)
+ * ------------------------------------------------------------------------- */
+
+enum {
+    FA_OK = 0,
+    FA_ERR_TILE = 1,      /* tile != 64            (wrapper.cu:53-57) */
+    FA_ERR_SEQLEN = 2,    /* L % tile != 0 or <= 0 (wrapper.cu:59-61) */
+    FA_ERR_HEAD_DIM = 3,  /* D != 128 (the reference hard-codes it: cuda_utils.cuh:11) */
+    FA_ERR_SHAPE = 4,     /* B or H <= 0, or sizes overflow */
+    FA_ERR_POINTER = 5,   /* NULL tensor pointer */
+    FA_ERR_RUNTIME = 6    /* HIP runtime / launch failure; text in fa_last_error() */
+};
+
+/* Same work and arguments as run_tensor_flash_attention, but returns a status
+ * instead of throwing; the two drop-in functions are thin shells over these. */
+int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
+               int D, int tile, void* stream, float* elapsed_ms);
+int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                         int H, int L, int D, int tile, void* stream, float* elapsed_ms);
+
+/* Blockwise forward: folds one K/V block of Lk keys into the carried online-
+ * softmax state of Lq query rows, the rule of testing.cu:91-96 /
+ * tensor_flash_attention.cu:158-170 applied across blocks instead of across
+ * 64-key tiles.  This is the compute step of the sequence-parallel ring.
+ *   dQ            [BH][Lq][128] fp16       dK, dV  [BH][Lk][128] fp16
+ *   o_acc         [BH][Lq][128] fp32 un-normalised accumulator
+ *   row_max       [BH][Lq] fp32 running max of score/sqrt(D)
+ *   row_sum       [BH][Lq] fp32 running sum of exp(score/sqrt(D)-row_max)
+ *   first != 0    ignore the incoming state (start from zero)
+ *   last  != 0    write dO = o_acc/row_sum as fp16 and leave the state untouched;
+ *                 otherwise update o_acc,row_max,row_sum and leave dO untouched
+ * Lq and Lk must be multiples of 64.  Asynchronous on `stream`. */
+int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
+                     float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int first, int last,
+                     void* stream);
+
+/* Device-side input generator of the reference's throughput driver
+ * (benchmark_tensor_flash_attention.cu:34-41,68-72): element i of the buffer
+ * becomes half(fmodf((float)((i*16807+seed)&0xFFFF),1024)/1024-0.5). */
+int fa_init_half(uint16_t* dptr, size_t n, unsigned long long seed, void* stream);
+
+/* Facts about the current device for the roofline denominator:
+ * compute units, max engine clock in kHz, and the dense fp16 MFMA peak in
+ * FLOP/s computed as CUs * 4 SIMDs * 1024 FLOP/clk/SIMD * clock
+ * (v_mfma_f32_32x32x16_f16: 32768 FLOP per 32 cycles per SIMD). */
+int fa_device_info(int* compute_units, int* clock_khz, double* fp16_dense_peak_flops);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* fa_last_error(void);
+
+/* Library version string. */
+const char* fa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#undef FA_DEFAULT
+#endif /* FLASH_ATTENTION_H */

@@ -1,0 +1,65 @@
+// Correctness driver: counterpart of the reference's
+// flash_attention_tensor_cores/testing.cu:134-248.  Same shape (B=1,H=1,L=64,
+// D=128 by default), same input recipe (mt19937(42), N(0,1)+0.5, draw order
+// Q[i],K[i],V[i]), same call (host-pointer entry point), same five printed
+// metrics and ten sample pairs.  Differences: the CPU reference comes from the
+// oracle library instead of being defined in this file, optional B H L
+// arguments, and a real exit status (non-zero when max-abs > 2e-3 or the
+// global relative error > 1e-3).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../include/flash_attention.h"
+
+extern "C" {
+uint16_t oracle_float_to_half(float f);
+float oracle_half_to_float(uint16_t h);
+int oracle_attention_cpu(const uint16_t* Q, const uint16_t* K, const uint16_t* V, float* O, int B, int H, int L,
+                         int D, int causal, int nthreads);
+void oracle_error_metrics(const float* ref, const float* test, size_t n, double* out);
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? std::atoi(argv[1]) : 1;
+    const int H = argc > 2 ? std::atoi(argv[2]) : 1;
+    const int L = argc > 3 ? std::atoi(argv[3]) : 64;
+    const int D = 128;
+    const int tile = 64;
+    const size_t n = (size_t)B * H * L * D;
+
+    std::vector<uint16_t> Qh(n), Kh(n), Vh(n), Oh(n);
+    std::mt19937 gen(42);
+    std::normal_distribution<float> dist(0.0f, 1.0f);
+    const float bias = 0.5f;
+    for (size_t i = 0; i < n; ++i) {
+        const float q = dist(gen) + bias, k = dist(gen) + bias, v = dist(gen) + bias;
+        Qh[i] = oracle_float_to_half(q);
+        Kh[i] = oracle_float_to_half(k);
+        Vh[i] = oracle_float_to_half(v);
+    }
+
+    float elapsed_ms = 0.0f;
+    run_tensor_flash_attention_host_half(Qh.data(), Kh.data(), Vh.data(), Oh.data(), B, H, L, D, tile, 0, &elapsed_ms);
+    std::printf("Kernel elapsed: %f ms\n", elapsed_ms);
+
+    std::vector<float> O_gpu(n), O_cpu(n, 0.0f);
+    for (size_t i = 0; i < n; ++i) O_gpu[i] = oracle_half_to_float(Oh[i]);
+    oracle_attention_cpu(Qh.data(), Kh.data(), Vh.data(), O_cpu.data(), B, H, L, D, 0, 0);
+
+    double m[5];
+    oracle_error_metrics(O_cpu.data(), O_gpu.data(), n, m);
+    std::printf("Mean Absolute Error: %f\n", m[0]);
+    std::printf("Max Absolute Error: %f\n", m[1]);
+    std::printf("Mean Relative Error: %f\n", m[2]);
+    std::printf("Max Relative Error: %f\n", m[3]);
+    std::printf("Global Relative Error: %f\n", m[4]);
+    for (int i = 0; i < 10; ++i) std::printf("O_cpu[%d] = %f, O_gpu[%d] = %f\n", i, O_cpu[i], i, O_gpu[i]);
+
+    const bool ok = m[1] <= 2e-3 && m[4] <= 1e-3;
+    std::printf("%s (max-abs <= 2e-3 and global relative <= 1e-3)\n", ok ? "PASS" : "FAIL");
+    return ok ? 0 : 1;
+}

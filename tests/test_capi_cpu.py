@@ -1,0 +1,86 @@
+"""CPU tier for the C ABI: the library loads without a GPU, exports every symbol
+include/flash_attention.h declares, and rejects bad arguments before touching
+the device (validation of wrapper.cu:53-61 plus the D=128 requirement)."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "flash_attention.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(run_tensor_flash_attention(?:_host_half)?|fa_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_drop_in_symbols():
+    names = declared_functions()
+    assert "run_tensor_flash_attention" in names
+    assert "run_tensor_flash_attention_host_half" in names
+    assert len(names) >= 8
+
+
+def test_library_exports_every_declared_symbol(fa):
+    L = fa.lib()
+    for name in declared_functions():
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert sorted(fa.EXPORTED_SYMBOLS) == declared_functions()
+
+
+def test_version_and_last_error(fa):
+    assert b"gfx950" in fa.lib().fa_version()
+    assert isinstance(fa.lib().fa_last_error(), bytes)
+
+
+def _call(fa, fn, B=1, H=1, L=64, D=128, tile=64, null=False):
+    buf = np.zeros(16, dtype=np.float16)
+    p = None if null else buf.ctypes.data_as(fa.HalfPtr)
+    return getattr(fa.lib(), fn)(p, p, p, p, B, H, L, D, tile, None, None)
+
+
+@pytest.mark.parametrize("fn", ["fa_forward", "fa_forward_host_half"])
+def test_argument_validation_happens_before_any_device_work(fa, fn):
+    L = fa.lib()
+    assert _call(fa, fn, tile=32) == 1 and b"tile must be 64" in L.fa_last_error()
+    assert _call(fa, fn, L=100) == 2 and b"divisible by tile" in L.fa_last_error()
+    assert _call(fa, fn, L=0) == 2
+    assert _call(fa, fn, D=64) == 3 and b"D must be 128" in L.fa_last_error()
+    assert _call(fa, fn, B=0) == 4
+    assert _call(fa, fn, H=-1) == 4
+    assert _call(fa, fn, null=True) == 5
+
+
+def test_block_entry_point_validation(fa):
+    L = fa.lib()
+    buf = np.zeros(16, dtype=np.float16)
+    f32 = np.zeros(16, dtype=np.float32)
+    h = buf.ctypes.data_as(fa.HalfPtr)
+    f = f32.ctypes.data_as(fa.FloatPtr)
+    assert L.fa_forward_block(h, h, h, h, f, f, f, 1, 64, 64, 64, 1, 1, None) == 3
+    assert L.fa_forward_block(h, h, h, h, f, f, f, 1, 96, 64, 128, 1, 1, None) == 2
+    assert L.fa_forward_block(h, h, h, h, f, f, f, 1, 64, 0, 128, 1, 1, None) == 2
+    assert L.fa_forward_block(h, h, h, h, f, f, f, 0, 64, 64, 128, 1, 1, None) == 4
+    assert L.fa_forward_block(None, h, h, h, f, f, f, 1, 64, 64, 128, 1, 1, None) == 5
+    assert L.fa_forward_block(h, h, h, None, f, f, f, 1, 64, 64, 128, 1, 1, None) == 5   # last needs dO
+    assert L.fa_forward_block(h, h, h, h, None, f, f, 1, 64, 64, 128, 1, 0, None) == 5   # state needed
+    assert L.fa_init_half(None, 10, 1, None) == 5
+
+
+def test_python_front_end_refuses_cpu_tensors(fa):
+    import torch
+
+    q = torch.zeros((1, 1, 64, 128), dtype=torch.float16)
+    with pytest.raises(fa.FlashAttentionError):
+        fa.attention(q, q, q)
+
+
+def test_flop_formula(fa):
+    # benchmark_tensor_flash_attention.cu:218
+    assert fa.attention_flops(32, 16, 512, 128) == 4.0 * 512 * 512 * 128 * 16 * 32
+    assert round(fa.attention_flops(1, 16, 16384, 128) / 1e12, 3) == 2.199
