@@ -50,6 +50,13 @@ def lib() -> ct.CDLL:
                 f"{LIB_PATH} not found: build it with flash-attention_amd/csrc/shared_compile.sh "
                 "(there is no CPU fallback)"
             )
+        # PyTorch ships a HIP runtime of its own (same SONAME as /opt/rocm's).  Two HIP runtimes in
+        # one process do not work, so when torch is installed its copy must be mapped first; the
+        # dynamic linker then binds this library to that copy as well.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ct.CDLL(LIB_PATH)
         sig = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 5 + [ct.c_void_p, FloatPtr]
         for name in ("run_tensor_flash_attention", "run_tensor_flash_attention_host_half"):

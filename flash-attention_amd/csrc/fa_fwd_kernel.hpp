@@ -65,17 +65,26 @@ struct FwdParams {
 };
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second.
-// Fed the same value twice, the two results hold {own, partner} in one half-wave and
-// {partner, own} in the other, so a commutative combine needs no select.
+// Fed the same value twice, the first result holds the low half-wave's value in every lane and the
+// second the high half-wave's, so a commutative combine needs no select.
+// (The results are copied to scalars before the bit casts: __builtin_bit_cast applied directly to
+// an element of the returned vector reads element 0 whatever the index.)
+__device__ __forceinline__ void half_wave_pair(float x, float& lo, float& hi) {
+    const unsigned a = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned u0 = r[0], u1 = r[1];
+    lo = __builtin_bit_cast(float, u0);
+    hi = __builtin_bit_cast(float, u1);
+}
 __device__ __forceinline__ float half_wave_max(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float lo, hi;
+    half_wave_pair(x, lo, hi);
+    return fmaxf(lo, hi);
 }
 __device__ __forceinline__ float half_wave_sum(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    float lo, hi;
+    half_wave_pair(x, lo, hi);
+    return lo + hi;
 }
 
 __device__ __forceinline__ half8 pack_half8(const f32x16& s, int base) {
