@@ -42,6 +42,7 @@ constexpr int kRowsPerWave = 32;  // query rows owned by one wave
 constexpr int kRowBytes = kHeadDim * 2;
 constexpr int kTileBytes = kKvTile * kRowBytes;  // 16 KiB
 constexpr int kLdsBytes = 4 * kTileBytes;        // K and V, two buffers each
+constexpr float kRescaleSlack = 8.0f;            // log2 units a row max may run ahead of its reference
 
 enum : int {
     kFlagLoadState = 1,   // start from (o_acc, row_max, row_sum) instead of zero
@@ -183,10 +184,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
     // ---- running state.  m is kept in the log2 domain (score * log2(e)/sqrt(D)); l is a per-lane
     //      partial sum over this lane's 32 keys of every tile (lanes l and l+32 are added at the end).
     f32x16 oacc[4];
-    float m_run, l_run;
+    float m_run, l_run, m_true;
     if (p.flags & kFlagLoadState) {
         const size_t srow = (size_t)head * p.lq + q_row;
         m_run = p.row_max[srow] * 1.44269504088896340736f;
+        m_true = m_run;
         l_run = hh == 0 ? p.row_sum[srow] : 0.0f;
         const float* oa = p.o_acc + srow * kHeadDim;
 #pragma unroll
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
             }
     } else {
         m_run = -1e30f;
+        m_true = -1e30f;
         l_run = 0.0f;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -235,26 +238,33 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1, qf[ks], s1, 0, 0, 0);
         }
 
-        // ---- online softmax for query (lane & 31); this lane holds 32 of the tile's 64 keys
+        // ---- online softmax for query (lane & 31); this lane holds 32 of the tile's 64 keys.
+        //      The running reference m_run only moves when some row's tile max exceeds it by more
+        //      than kRescaleSlack (log2 units): p then stays below 2^kRescaleSlack, well inside
+        //      fp16, and the 64-register rescale of the accumulator is skipped on most tiles.
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
-        mx = half_wave_max(mx);
-        const float m_new = fmaxf(m_run, mx * c);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        mx = half_wave_max(mx) * c;
+        m_true = fmaxf(m_true, mx);
+        if (!__all(mx - m_run <= kRescaleSlack)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+        }
         float rowsum = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], c, -m_new));
-            s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, -m_new));
+            s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], c, -m_run));
+            s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, -m_run));
             rowsum += s0[e] + s1[e];
         }
-        l_run = l_run * alpha + rowsum;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+        l_run += rowsum;
 
         // P^T fragments: registers 8s..8s+7 of a 32-key block are k-step s of that block, with
         // element j of lane half hh being key 16s + 8(j>>2) + 4hh + (j&3)
@@ -285,12 +295,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
     }
 
     // ---- epilogue
-    const float l_tot = half_wave_sum(l_run);
     if (!wave_valid) return;
     const size_t srow = (size_t)head * p.lq + q_row;
     if (p.flags & kFlagStoreState) {
+        // hand the state over relative to the true running max, whatever reference was in use
+        const float beta = __builtin_amdgcn_exp2f(m_run - m_true);
+        const float l_tot = half_wave_sum(l_run) * beta;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[db][e] *= beta;
         if (hh == 0) {
-            p.row_max[srow] = m_run * 0.69314718055994530942f;
+            p.row_max[srow] = m_true * 0.69314718055994530942f;
             p.row_sum[srow] = l_tot;
         }
         float* oa = p.o_acc + srow * kHeadDim;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
                 *reinterpret_cast<f32x4*>(oa + 32 * db + 8 * g4 + 4 * hh) = t;
             }
     } else {
-        const float inv = 1.0f / l_tot;
+        const float inv = 1.0f / half_wave_sum(l_run);
         half_t* og = p.o + srow * kHeadDim;
 #pragma unroll
         for (int db = 0; db < 4; ++db)

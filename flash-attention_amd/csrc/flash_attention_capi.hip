@@ -34,21 +34,22 @@ int fail(int code, const char* fmt, const char* detail = "") {
         }                                                                                 \
     } while (0)
 
-// Workgroup size: 8 waves (256 query rows) halve the K/V traffic per query row and are the
-// default; 4 waves are used when 8 would not divide the rows or would leave CUs idle.
-int pick_waves(int bh, int lq) {
+// Workgroup size.  8 waves (256 query rows) read each K/V tile from L2 half as often per query
+// row and win from L = 2048 up; below that a head has few key tiles, the per-workgroup prologue
+// and epilogue dominate, and two independent 4-wave workgroups per CU overlap them better.
+int pick_waves(int bh, int lq, int lk) {
     if (const char* e = std::getenv("FA_NWAVES")) {
         const int n = std::atoi(e);
         if (n == 4 || n == 8) return n;
     }
-    if (lq % 256 != 0) return 4;
+    if (lq % 256 != 0 || lk <= 1024) return 4;
     const long blocks8 = (long)bh * (lq / 256);
     return blocks8 >= 512 ? 8 : 4;
 }
 
 int launch(const fa::FwdParams& base, hipStream_t stream) {
     fa::FwdParams p = base;
-    const int nw = pick_waves(p.bh, p.lq);
+    const int nw = pick_waves(p.bh, p.lq, p.lk);
     const int qb_rows = nw * fa::kRowsPerWave;
     p.q_blocks = (p.lq + qb_rows - 1) / qb_rows;
     const long grid = (long)p.bh * p.q_blocks;

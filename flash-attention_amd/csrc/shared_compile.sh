@@ -6,7 +6,7 @@ set -euo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT_LIB=${OUT_LIB:-libflash_attention.so}
-"$HIPCC" -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared \
+"$HIPCC" -O3 -std=c++17 --offload-arch=gfx950 -fno-honor-nans -fPIC -shared \
     -Wall -Wno-unused-result \
     -o "$OUT_LIB" flash_attention_capi.hip
 echo "built $OUT_LIB"
