@@ -89,9 +89,12 @@ def cpu_baseline(B, H, L, target_s):
     n_heads = int(max(1, min(B * H, target_s / t_probe)))
     n = n_heads * L * D
     Q, K, V = [oracle.init_half(n, s).reshape(1, n_heads, L, D) for s in (1234, 2345, 3456)]
+    # when even the whole workload is short on this host, repeat it until ~target_s has been spent
+    reps = int(max(1, min(50, target_s / max(t_probe * n_heads, 1e-3))))
     t = time.perf_counter()
-    oracle.attention_cpu(Q, K, V, nthreads=0)
-    dt = time.perf_counter() - t
+    for _ in range(reps):
+        oracle.attention_cpu(Q, K, V, nthreads=0)
+    dt = (time.perf_counter() - t) / reps
     # the literal single-threaded loop nest of the reference, on one head of at most 512 rows
     Ls = min(L, 512)
     t = time.perf_counter()
@@ -104,10 +107,25 @@ def cpu_baseline(B, H, L, target_s):
         "cores": threads,
         "kind": "port",
         "sample": f"{n_heads} of {B * H} (batch,head) slices of the workload (L={L}, D={D}), "
-                  f"{n_heads * per_head / 1e9:.1f} GFLOP in {dt:.2f} s on {threads} OpenMP threads",
+                  f"{n_heads * per_head / 1e9:.1f} GFLOP in {dt:.3f} s on {threads} OpenMP threads, mean of {reps} passes",
         "host_cpus": os.cpu_count(),
         "literal_single_thread_gflops": 4.0 * Ls * Ls * D / dt_lit / 1e9,
     }
+
+
+def measured_traffic(L):
+    """HBM bytes per launch of this shape from the newest committed rocprofv3 counter summary
+    (profiles/*_L<L>.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
+    WRITE_SIZE passes); None when this shape has not been profiled."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_L{L}.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["hbm_bytes"])
+    except Exception:
+        return None
 
 
 def main():
@@ -151,17 +169,11 @@ def main():
     # inputs: the driver's pattern depends only on the flat element index; a strong-scaling shard
     # gets its own window of the global tensors
     n_local = bh_local * L * D
-    q = torch.empty((1, bh_local, L, D), dtype=torch.float16, device=dev)
-    k, v, o = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-    if head0 == 0:
-        fa.init_half(q, 1234), fa.init_half(k, 2345), fa.init_half(v, 3456)
-    else:
-        import numpy as np
-
-        import oracle
-
-        for t, s in ((q, 1234), (k, 2345), (v, 3456)):
-            t.copy_(torch.from_numpy(oracle.init_half(n_local, s, idx0=head0 * L * D).reshape(t.shape)))
+    full = [torch.empty((BH_total, L, D), dtype=torch.float16, device=dev) for _ in range(3)]
+    for t, seed in zip(full, (1234, 2345, 3456)):
+        fa.init_half(t, seed)
+    q, k, v = [t[head0:head0 + bh_local].reshape(1, bh_local, L, D) for t in full]  # contiguous slabs
+    o = torch.empty_like(q)
     torch.cuda.synchronize()
 
     wall, ms_launch = time_steps(fa, torch, q, k, v, o, args.steps, args.warmup, barrier)
@@ -203,7 +215,7 @@ def main():
             "peak": PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": measured_traffic(L),
             "kernel": "fa::fa_fwd_kernel",
             "kernel_ms": ms_launch,
             "algorithmic_bytes": 4 * n_local * 2,

@@ -1,0 +1,102 @@
+"""Multi-GPU drivers for the forward-attention path: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI) as plumbing.
+
+The reference has no multi-device code (README.md:47 lists it as future work), so
+nothing here mirrors a reference file; the two modes follow from the math:
+
+* Head sharding.  Every (batch, head) pair is an independent attention problem
+  (the reference kernel's grid axes blockIdx.y / blockIdx.z,
+  tensor_flash_attention.cu:30-31) and one head is one contiguous L*D slab of each
+  tensor, so a rank's shard is a contiguous range of the flattened [B*H] axis and the
+  data path needs no collective at all.
+
+* Sequence-parallel ring.  Rank r owns rows [r*L/P, (r+1)*L/P) of Q, K, V and O for
+  all heads.  In P steps each K/V block visits every rank once: at step s rank r holds
+  block (r - s) mod P, folds it into its carried (O, m, l) with the blockwise entry
+  point, and meanwhile passes it to rank r+1 with a send/recv pair.  The merge rule is
+  the online-softmax rescale of testing.cu:91-96 applied across blocks.  Non-causal
+  attention makes every step the same amount of work on every rank.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+
+def head_shard(total_heads: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) range of the flattened B*H axis owned by ``rank``.
+    The first ``total_heads % world`` ranks get one extra head."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(total_heads, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def sharded_forward(q, k, v, rank: int, world: int, attention_fn: Optional[Callable] = None):
+    """Run this rank's head shard.  q,k,v: the GLOBAL [B,H,L,D] tensors (or any tensors whose
+    flattened B*H axis is global); returns (start, stop, O_shard [1, stop-start, L, D]).
+    No communication."""
+    B, H, L, D = q.shape
+    start, stop = head_shard(B * H, world, rank)
+    if attention_fn is None:
+        import flash_attention_amd as fa
+
+        attention_fn = fa.attention
+    qs = q.reshape(1, B * H, L, D)[:, start:stop].contiguous()
+    ks = k.reshape(1, B * H, L, D)[:, start:stop].contiguous()
+    vs = v.reshape(1, B * H, L, D)[:, start:stop].contiguous()
+    return start, stop, attention_fn(qs, ks, vs)
+
+
+def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_factory: Optional[Callable] = None):
+    """Sequence-parallel forward.  q,k,v: this rank's rows, contiguous [B,H,L/P,D].
+    Returns this rank's rows of O.
+
+    ``step_fn(q, k_blk, v_blk, state, last)`` folds one K/V block into ``state`` and returns
+    the output on the last step; ``state_factory(BH, Lq, D, device)`` creates the carried state.
+    Both default to the HIP library (GPU tensors required).  Tests inject CPU stand-ins to
+    exercise the communication schedule under the gloo backend.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if step_fn is None or state_factory is None:
+        import flash_attention_amd as fa
+
+        step_fn = step_fn or fa.attention_block
+        state_factory = state_factory or fa.BlockState
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    B, H, Lq, D = q.shape
+    state = state_factory(B * H, Lq, D, q.device)
+    if world == 1:
+        return step_fn(q, k, v, state, True)
+
+    nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
+    prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
+
+    # K and V travel as one message: [2, B, H, Lk, D]
+    cur = torch.stack((k, v)).contiguous()
+    spare = torch.empty_like(cur)
+    out = None
+    for s in range(world):
+        last = s == world - 1
+        reqs = []
+        if not last:
+            # issued before the compute of this step, so the transfer overlaps it; the
+            # backend orders it after the previous step's kernel, which was the last reader
+            # of `spare`
+            ops = [dist.P2POp(dist.isend, cur, nxt, group), dist.P2POp(dist.irecv, spare, prv, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        out = step_fn(q, cur[0], cur[1], state, last)
+        for r in reqs:
+            r.wait()
+        if not last:
+            cur, spare = spare, cur
+    return out
+
+
+def ring_block_order(rank: int, world: int):
+    """Index of the K/V block rank ``rank`` holds at each step."""
+    return [(rank - s) % world for s in range(world)]

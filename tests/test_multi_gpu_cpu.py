@@ -1,0 +1,128 @@
+"""CPU tier for the N>1 paths: world_size-2 (and 4) gloo runs of the head-sharded and the
+ring drivers, with the GPU compute step replaced by the CPU oracle so that only the
+partitioning and the communication schedule are under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, normal_fp16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _load():
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    import __graft_entry__ as ge
+    import oracle
+
+    ge.load_package()
+    return importlib.import_module("flash_attention_amd.multi_gpu"), oracle
+
+
+class _CpuState:
+    def __init__(self, BH, Lq, D, device):
+        self.inner = None
+
+
+def _make_step(oracle, B, H):
+    def step(q, kb, vb, state, last):
+        Q, K, V = [np.ascontiguousarray(t.numpy()) for t in (q, kb, vb)]
+        if state.inner is None:
+            state.inner = oracle.BlockState(B, H, Q.shape[2], Q.shape[3])
+        oracle.block_update(state.inner, Q, K, V, nthreads=1)
+        return torch.from_numpy(oracle.block_finalize(state.inner)) if last else None
+
+    return step
+
+
+def _ring_worker(rank, world, port, out_dir):
+    mg, oracle = _load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        B, H, L, D = 1, 2, 64 * 2 * world, 128
+        Q, K, V = normal_fp16(100, (B, H, L, D))
+        n = L // world
+        sl = slice(rank * n, (rank + 1) * n)
+        q, k, v = [torch.from_numpy(np.ascontiguousarray(a[:, :, sl])) for a in (Q, K, V)]
+        out = mg.ring_forward(q, k, v, step_fn=_make_step(oracle, B, H), state_factory=_CpuState)
+        ref = oracle.attention_cpu(Q, K, V, nthreads=1)[:, :, sl]
+        m = oracle.error_metrics(ref, out.numpy())
+        ok = m["max_abs"] < 3e-4 and m["global_rel"] < 3e-4
+        # inputs must come back untouched (the ring only reads them)
+        ok = ok and np.array_equal(k.numpy(), K[:, :, sl]) and np.array_equal(v.numpy(), V[:, :, sl])
+        open(os.path.join(out_dir, f"ring_{rank}.txt"), "w").write(f"{int(ok)} {m['max_abs']:.3e} {m['global_rel']:.3e}")
+    finally:
+        dist.destroy_process_group()
+
+
+def _shard_worker(rank, world, port, out_dir):
+    mg, oracle = _load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        B, H, L, D = 3, 3, 128, 128   # 9 heads over 2 ranks: uneven split
+        Q, K, V = normal_fp16(101, (B, H, L, D))
+        attn = lambda q, k, v: torch.from_numpy(oracle.attention_cpu(*[np.ascontiguousarray(t.numpy()) for t in (q, k, v)], nthreads=1))
+        start, stop, o = mg.sharded_forward(*[torch.from_numpy(a) for a in (Q, K, V)], rank, world, attention_fn=attn)
+        ref = oracle.attention_cpu(Q, K, V, nthreads=1).reshape(1, B * H, L, D)[:, start:stop]
+        ok = np.array_equal(ref.view(np.uint32), o.numpy().view(np.uint32))
+        # the timing reduction bench.py uses: max over ranks
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and t.item() == float(world)
+        open(os.path.join(out_dir, f"shard_{rank}.txt"), "w").write(f"{int(ok)} {start} {stop}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ring_forward_gloo(tmp_path, world):
+    mp.spawn(_ring_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, *rest = open(tmp_path / f"ring_{r}.txt").read().split()
+        assert ok == "1", (r, rest)
+
+
+def test_head_sharded_forward_gloo(tmp_path):
+    world = 2
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [open(tmp_path / f"shard_{r}.txt").read().split() for r in range(world)]
+    assert [g[0] for g in got] == ["1", "1"]
+    assert (got[0][1], got[0][2], got[1][1], got[1][2]) == ("0", "5", "5", "9")
+
+
+def test_head_shard_partition_properties():
+    mg, _ = _load()
+    for total in (1, 7, 16, 512):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [mg.head_shard(total, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    # C4: 16 heads over 1/2/4/8 GPUs
+    assert [mg.head_shard(16, w, w - 1) for w in (1, 2, 4, 8)] == [(0, 16), (8, 16), (12, 16), (14, 16)]
+    with pytest.raises(ValueError):
+        mg.head_shard(4, 2, 2)
+
+
+def test_ring_block_order():
+    mg, _ = _load()
+    assert mg.ring_block_order(0, 4) == [0, 3, 2, 1]
+    assert mg.ring_block_order(2, 4) == [2, 1, 0, 3]
+    for w in (2, 8):
+        for r in range(w):
+            assert sorted(mg.ring_block_order(r, w)) == list(range(w))

@@ -258,3 +258,16 @@ def test_cpp_correctness_driver():
     assert "Global Relative Error" in r.stdout and "PASS" in r.stdout
     r = subprocess.run([exe, "2", "3", "320"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_compare_impls_counterpart():
+    """The ctypes caller flow of benchmarks/compare_impls.py (same argtypes, same recipe) against
+    the torch fp32 softmax reference: the reference kernel recorded MAE 6.05e-5 / MRE 7.6e-3."""
+    script = os.path.join(ROOT, "flash-attention_amd", "benchmarks", "compare_impls.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("Tensor Cores: MAE=")][0]
+    mae = float(line.split("MAE=")[1].split()[0])
+    mre = float(line.split("MRE=")[1])
+    assert mae < 1e-4 and mre < 1.5e-2, line
+    assert "Speed (ms)" in r.stdout
