@@ -41,7 +41,7 @@ constexpr int kKvTile = 64;       // keys per streamed tile (the ABI's `tile`)
 constexpr int kRowsPerWave = 32;  // query rows owned by one wave
 constexpr int kRowBytes = kHeadDim * 2;
 constexpr int kTileBytes = kKvTile * kRowBytes;  // 16 KiB
-constexpr int kLdsBytes = 4 * kTileBytes;        // K and V, two buffers each
+constexpr int kLdsBytes = 4 * kTileBytes;        // K and V, two buffers each (the per-wave staging images follow)
 constexpr float kRescaleSlack = 8.0f;            // log2 units a row max may run ahead of its reference
 
 enum : int {
@@ -63,6 +63,7 @@ struct FwdParams {
     int q_blocks;     // ceil(lq / (NWAVES*32))
     float scale_log2e;  // log2(e)/sqrt(D)
     int flags;
+    unsigned long long* stamps;  // diagnostic builds only (FA_STAMPS): 32 time stamps per workgroup
 };
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second.
@@ -95,110 +96,136 @@ __device__ __forceinline__ half8 pack_half8(const f32x16& s, int base) {
     return __builtin_convertvector(t, half8);
 }
 
-template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams p) {
-    constexpr int NT = NWAVES * 64;
-    constexpr int QB = NWAVES * kRowsPerWave;
-    constexpr int CHUNKS = (kTileBytes / 16) / NT;  // 16-byte chunks per thread per tile
-    static_assert(CHUNKS >= 1, "too many threads for one tile");
+// ---------------------------------------------------------------------------------------------
+// Per-lane constants shared by the tile routines.
+// ---------------------------------------------------------------------------------------------
+struct LaneGeom {
+    int r;        // lane & 31: query row inside the wave / operand row
+    int hh;       // lane >> 5: which half of each k-step this lane feeds
+    int k_rd[8];  // K operand read: row r, chunk (2ks+hh) ^ (r&15)
+    int v_rd[4];  // V transposed read, per 32-column output block
+};
 
-    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31;   // query row inside the wave / operand row
-    const int hh = lane >> 5;  // which half of each k-step this lane feeds
-
-    // ---- workgroup -> (head, query block).  Workgroups are dealt round-robin over the 8 XCDs,
-    //      so ids congruent mod 8 share an L2: give all query blocks of one head one residue.
-    int head, qb;
-    {
-        const int bid = blockIdx.x;
-        if ((p.bh & 7) == 0) {
-            const int j = bid >> 3;
-            head = (j / p.q_blocks) * 8 + (bid & 7);
-            qb = j % p.q_blocks;
-        } else {
-            head = bid / p.q_blocks;
-            qb = bid % p.q_blocks;
-        }
-    }
-    const size_t q_head_off = (size_t)head * p.lq * kHeadDim;
-    const size_t k_head_off = (size_t)head * p.lk * kHeadDim;
-    const half_t* __restrict__ qg = p.q + q_head_off;
-    const half_t* __restrict__ kg = p.k + k_head_off;
-    const half_t* __restrict__ vg = p.v + k_head_off;
-
-    const int q_row0 = qb * QB + wave * kRowsPerWave;
-    const bool wave_valid = q_row0 < p.lq;  // wave-uniform; invalid waves still stage K/V
-    const int q_row = (wave_valid ? q_row0 : 0) + r;
-
-    // ---- Q fragments: B operand of S^T = K.Q^T.  Lane (r,hh) holds Q[r][16ks+8hh .. +7].
-    half8 qf[8];
+__device__ __forceinline__ LaneGeom make_lane_geom(int lane) {
+    LaneGeom g;
+    g.r = lane & 31;
+    g.hh = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        qf[ks] = *reinterpret_cast<const half8*>(qg + (size_t)q_row * kHeadDim + ks * 16 + hh * 8);
-
-    // ---- staging geometry: thread t moves 16-byte chunk (t + i*NT) of a tile, i.e. row
-    //      (t>>4) + i*RSTEP, chunk t&15.  RSTEP is a multiple of 16, so the swizzle term is the
-    //      same for every i and the per-i offsets are compile-time constants.
-    constexpr int RSTEP = NT / 16;
-    const int st_row = tid >> 4, st_ch = tid & 15;
-    const int st_goff = st_row * kHeadDim + st_ch * 8;                          // elements
-    const int st_koff = st_row * kRowBytes + ((st_ch ^ (st_row & 15)) << 4);    // bytes in a K buffer
-    const int st_voff = st_row * kRowBytes + ((st_ch ^ ((st_row & 3) << 2)) << 4);  // bytes in a V buffer
-    u32x4 st_k[CHUNKS], st_v[CHUNKS];
-
-#define FA_STAGE_LOAD(tile)                                                                     \
-    do {                                                                                        \
-        const half_t* kt = kg + (size_t)(tile) * (kKvTile * kHeadDim) + st_goff;                \
-        const half_t* vt = vg + (size_t)(tile) * (kKvTile * kHeadDim) + st_goff;                \
-        _Pragma("unroll") for (int i = 0; i < CHUNKS; ++i) {                                    \
-            st_k[i] = *reinterpret_cast<const u32x4*>(kt + i * RSTEP * kHeadDim);               \
-            st_v[i] = *reinterpret_cast<const u32x4*>(vt + i * RSTEP * kHeadDim);               \
-        }                                                                                       \
-    } while (0)
-#define FA_STAGE_WRITE(buf)                                                                     \
-    do {                                                                                        \
-        char* kw = smem + (buf) * 2 * kTileBytes;                                               \
-        _Pragma("unroll") for (int i = 0; i < CHUNKS; ++i) {                                    \
-            *reinterpret_cast<u32x4*>(kw + st_koff + i * RSTEP * kRowBytes) = st_k[i];          \
-            *reinterpret_cast<u32x4*>(kw + kTileBytes + st_voff + i * RSTEP * kRowBytes) = st_v[i]; \
-        }                                                                                       \
-    } while (0)
-
-    // ---- operand read addresses (per lane, tile- and buffer-independent parts)
-    // K: row r (and r+32), chunk (2ks+hh) ^ (r&15)
-    int k_rd[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r * kRowBytes + (((2 * ks + hh) ^ (r & 15)) << 4);
-    // V (transposed read): lane = 16g + 4q + pp supplies row (4hh+q) [+16kk, +8], 8 bytes at
-    // chunk (4db + 2(g&1) + (pp>>1)) ^ (q<<2), byte 8(pp&1)
+    for (int ks = 0; ks < 8; ++ks) g.k_rd[ks] = g.r * kRowBytes + (((2 * ks + g.hh) ^ (g.r & 15)) << 4);
+    // lane = 16g + 4q + pp supplies row (4hh+q) [+16kk, +8], 8 bytes at chunk
+    // (4db + 2(g&1) + (pp>>1)) ^ (q<<2), byte 8(pp&1)
     const int tq = (lane >> 2) & 3, tp = lane & 3, tcg = (lane >> 4) & 1;
-    int v_rd[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
-        v_rd[db] = (4 * hh + tq) * kRowBytes + ((((4 * db) ^ (tq << 2)) + 2 * tcg + (tp >> 1)) << 4) + 8 * (tp & 1);
+        g.v_rd[db] =
+            (4 * g.hh + tq) * kRowBytes + ((((4 * db) ^ (tq << 2)) + 2 * tcg + (tp >> 1)) << 4) + 8 * (tp & 1);
+    return g;
+}
 
-    // ---- running state.  m is kept in the log2 domain (score * log2(e)/sqrt(D)); l is a per-lane
-    //      partial sum over this lane's 32 keys of every tile (lanes l and l+32 are added at the end).
-    f32x16 oacc[4];
-    float m_run, l_run, m_true;
-    if (p.flags & kFlagLoadState) {
-        const size_t srow = (size_t)head * p.lq + q_row;
-        m_run = p.row_max[srow] * 1.44269504088896340736f;
-        m_true = m_run;
-        l_run = hh == 0 ? p.row_sum[srow] : 0.0f;
-        const float* oa = p.o_acc + srow * kHeadDim;
+// Q fragments: B operand of S^T = K.Q^T.  Lane (r,hh) holds Q[row][16ks+8hh .. +7].
+__device__ __forceinline__ void load_q_frags(half8 (&qf)[8], const half_t* q_row_ptr, int hh) {
+#pragma unroll
+#ifdef FA_ABLATE_CHEAP_Q
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const half8*>(q_row_ptr + hh * 8);
+#else
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const half8*>(q_row_ptr + ks * 16 + hh * 8);
+#endif
+}
+
+// S^T = K.Q^T : two 32-key blocks, 8 k-steps of 16 over D
+__device__ __forceinline__ void qk_tile(const char* kb, const LaneGeom& g, const half8 (&qf)[8], f32x16& s0,
+                                        f32x16& s1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        s0[e] = 0.0f;
+        s1[e] = 0.0f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const half8 ka0 = *reinterpret_cast<const half8*>(kb + g.k_rd[ks]);
+        const half8 ka1 = *reinterpret_cast<const half8*>(kb + g.k_rd[ks] + 32 * kRowBytes);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka0, qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1, qf[ks], s1, 0, 0, 0);
+    }
+}
+
+// Online softmax for query (lane & 31); this lane holds 32 of the tile's 64 keys.  The running
+// reference m_run only moves when some row's tile max exceeds it by more than kRescaleSlack (log2
+// units): p then stays below 2^kRescaleSlack, well inside fp16, and the 64-register rescale of the
+// accumulator is skipped on most tiles.  On return s0/s1 hold p and pf the fp16 P^T fragments:
+// registers 8s..8s+7 of a 32-key block are k-step s of that block, element j of lane half hh being
+// key 16s + 8(j>>2) + 4hh + (j&3).
+__device__ __forceinline__ void softmax_tile(f32x16& s0, f32x16& s1, float c, float& m_run, float& m_true,
+                                             float& l_run, f32x16 (&oacc)[4], half8 (&pf)[4]) {
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+    mx = half_wave_max(mx) * c;
+    m_true = fmaxf(m_true, mx);
+    if (!__all(mx - m_run <= kRescaleSlack)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(oa + 32 * db + 8 * g4 + 4 * hh);
+            for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+    }
+    float rowsum = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) oacc[db][4 * g4 + e] = t[e];
-            }
+    for (int e = 0; e < 16; ++e) {
+        s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], c, -m_run));
+        s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, -m_run));
+        rowsum += s0[e] + s1[e];
+    }
+    l_run += rowsum;
+    pf[0] = pack_half8(s0, 0);
+    pf[1] = pack_half8(s0, 8);
+    pf[2] = pack_half8(s1, 0);
+    pf[3] = pack_half8(s1, 8);
+}
+
+// O^T += V^T.P^T : 4 k-steps of 16 keys x 4 blocks of 32 output columns
+__device__ __forceinline__ void pv_tile(const char* vb, const LaneGeom& g, const half8 (&pf)[4], f32x16 (&oacc)[4]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const char* a0 = vb + g.v_rd[db] + kk * 16 * kRowBytes;
+            const short4_t t0 =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a0));
+            const short4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(a0 + 8 * kRowBytes));
+            const half8 vf = __builtin_bit_cast(half8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], oacc[db], 0, 0, 0);
+        }
+    }
+}
+
+// Running state.  m is kept in the log2 domain (score * log2(e)/sqrt(D)); l is a per-lane partial sum
+// over this lane's 32 keys of every tile (lanes l and l+32 are added at the end).
+__device__ __forceinline__ void init_state(const FwdParams& p, size_t srow, int hh, f32x16 (&oacc)[4],
+                                           float& m_run, float& m_true, float& l_run) {
+    if (p.flags & kFlagLoadState) {
+        float mx = p.row_max[srow], sm = p.row_sum[srow];
+        const float* oa = p.o_acc + srow * kHeadDim;
+        f32x4 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = *reinterpret_cast<const f32x4*>(oa + 32 * (i >> 2) + 8 * (i & 3) + 4 * hh);
+        // Wait for these loads HERE.  Left pending, the accumulator registers would carry "may be
+        // in flight" into the tile code, and the waits the compiler then puts in front of the first
+        // uses would also drain the tile and Q prefetches issued in between.
+        asm volatile("" : "+v"(mx), "+v"(sm));
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) asm volatile("" : "+v"(t[i]), "+v"(t[i + 1]), "+v"(t[i + 2]), "+v"(t[i + 3]));
+        m_run = mx * 1.44269504088896340736f;
+        m_true = m_run;
+        l_run = hh == 0 ? sm : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[i >> 2][4 * (i & 3) + e] = t[i][e];
     } else {
         m_run = -1e30f;
         m_true = -1e30f;
@@ -208,103 +235,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[db][e] = 0.0f;
     }
+}
 
-    const int n_tiles = p.lk / kKvTile;
-    const float c = p.scale_log2e;
-
-    FA_STAGE_LOAD(0);
-    FA_STAGE_WRITE(0);
-    __syncthreads();
-
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) FA_STAGE_LOAD(t + 1);
-
-        const char* kb = smem + buf * 2 * kTileBytes;
-        const char* vb = kb + kTileBytes;
-
-        // ---- S^T = K.Q^T : two 32-key blocks, 8 k-steps of 16 over D
-        f32x16 s0, s1;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s0[e] = 0.0f;
-            s1[e] = 0.0f;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const half8 ka0 = *reinterpret_cast<const half8*>(kb + k_rd[ks]);
-            const half8 ka1 = *reinterpret_cast<const half8*>(kb + k_rd[ks] + 32 * kRowBytes);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1, qf[ks], s1, 0, 0, 0);
-        }
-
-        // ---- online softmax for query (lane & 31); this lane holds 32 of the tile's 64 keys.
-        //      The running reference m_run only moves when some row's tile max exceeds it by more
-        //      than kRescaleSlack (log2 units): p then stays below 2^kRescaleSlack, well inside
-        //      fp16, and the 64-register rescale of the accumulator is skipped on most tiles.
-        float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
-        mx = half_wave_max(mx) * c;
-        m_true = fmaxf(m_true, mx);
-        if (!__all(mx - m_run <= kRescaleSlack)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
-        }
-        float rowsum = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], c, -m_run));
-            s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, -m_run));
-            rowsum += s0[e] + s1[e];
-        }
-        l_run += rowsum;
-
-        // P^T fragments: registers 8s..8s+7 of a 32-key block are k-step s of that block, with
-        // element j of lane half hh being key 16s + 8(j>>2) + 4hh + (j&3)
-        half8 pf[4];
-        pf[0] = pack_half8(s0, 0);
-        pf[1] = pack_half8(s0, 8);
-        pf[2] = pack_half8(s1, 0);
-        pf[3] = pack_half8(s1, 8);
-
-        // ---- O^T += V^T.P^T : 4 k-steps of 16 keys x 4 blocks of 32 output columns
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const char* a0 = vb + v_rd[db] + kk * 16 * kRowBytes;
-                const short4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4_t*)(a0));
-                const short4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4_t*)(a0 + 8 * kRowBytes));
-                const half8 vf = __builtin_bit_cast(
-                    half8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], oacc[db], 0, 0, 0);
-            }
-        }
-
-        if (t + 1 < n_tiles) FA_STAGE_WRITE(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue
-    if (!wave_valid) return;
-    const size_t srow = (size_t)head * p.lq + q_row;
+// Lane (q = lane&31, hh) holds output row q, columns 32db + 8g4 + 4hh + (0..3) in oacc[db][4g4..4g4+3].
+__device__ __forceinline__ void finish_rows(const FwdParams& p, size_t srow, int hh, f32x16 (&oacc)[4],
+                                            float m_run, float m_true, float l_run) {
     if (p.flags & kFlagStoreState) {
         // hand the state over relative to the true running max, whatever reference was in use
         const float beta = __builtin_amdgcn_exp2f(m_run - m_true);
         const float l_tot = half_wave_sum(l_run) * beta;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[db][e] *= beta;
         if (hh == 0) {
             p.row_max[srow] = m_true * 0.69314718055994530942f;
             p.row_sum[srow] = l_tot;
@@ -316,7 +255,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
             for (int g4 = 0; g4 < 4; ++g4) {
                 f32x4 t;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * g4 + e];
+                for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * g4 + e] * beta;
                 *reinterpret_cast<f32x4*>(oa + 32 * db + 8 * g4 + 4 * hh) = t;
             }
     } else {
@@ -329,11 +268,270 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
                 f32x4 t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * g4 + e] * inv;
+#ifdef FA_ABLATE_NO_STORE
+                asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+#else
                 *reinterpret_cast<half4*>(og + 32 * db + 8 * g4 + 4 * hh) = __builtin_convertvector(t, half4);
+#endif
             }
     }
 }
 
+// Work item -> (head, query block).  Workgroups are dealt round-robin over the 8 XCDs, so ids
+// congruent mod 8 share an L2: all query blocks of one head get one residue class, and the head's
+// K/V are re-read from that L2.
+__device__ __forceinline__ void decode_item(const FwdParams& p, int item, int& head, int& qb) {
+    if ((p.bh & 7) == 0) {
+        const int j = item >> 3;
+        head = (j / p.q_blocks) * 8 + (item & 7);
+        qb = j % p.q_blocks;
+    } else {
+        head = item / p.q_blocks;
+        qb = item % p.q_blocks;
+    }
+}
+
+// Per-wave LDS staging image (32 rows x 256 B, chunk c of row q at q*256 + ((c ^ (q&15)) << 4)):
+// the same image serves the coalesced write-out of an output tile and the coalesced read-in of the
+// next item's Q rows.  In both directions one side touches it fragment-wise (lane = row) and the
+// other row-wise (16 lanes per row, 4 whole rows per wave instruction); the XOR keeps both free of
+// bank conflicts.  Only the owning wave touches its image, and a wave's LDS operations execute in
+// order, so no barrier is involved.
+__device__ __forceinline__ int stage_img_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ (row & 15)) << 4); }
+
+// The item-boundary code runs once per item but sits inside the loop over items, so the optimiser
+// would hoist its two dozen lane-constant addresses out and keep them in registers across the tile
+// loop, which has none to spare.  Passing the lane id through an empty asm makes them recomputed
+// where they are used.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// O = acc / l as fp16, written through the staging image so that global stores are whole rows.
+__device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
+                                                  float l_run) {
+    const float inv = 1.0f / half_wave_sum(l_run);
+    lane = opaque(lane);
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * g4 + e] * inv;
+            // columns 32db + 8g4 + 4hh .. +3  =  chunk 4db+g4, second half when hh
+            *reinterpret_cast<half4*>(img + stage_img_off(r, 4 * db + g4) + 8 * hh) = __builtin_convertvector(t, half4);
+        }
+    const int row0 = lane >> 4, ch = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + row0;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(img + stage_img_off(row, ch));
+#ifdef FA_ABLATE_NO_STORE
+        asm volatile("" ::"v"(v));
+#else
+        *reinterpret_cast<u32x4*>(o_rows + row * kHeadDim + ch * 8) = v;
+#endif
+    }
+}
+
+// Next item's Q rows travel global -> LDS directly (global_load_lds_dwordx4: no registers, 4 whole
+// rows per wave instruction).  The LDS side of such a load is linear (piece base + 16*lane), so the
+// image's XOR swizzle is applied to the SOURCE address: lane l of piece i fills slot l&15 of row
+// 4i + (l>>4) with chunk (l&15) ^ (row&15).
+__device__ __forceinline__ void dma_q_rows(const half_t* q_rows, char* img, int lane) {
+    lane = opaque(lane);
+    const int row0 = lane >> 4, slot = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + row0;
+        const half_t* src = q_rows + row * kHeadDim + ((slot ^ (row & 15)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
+    }
+}
+// They are picked up as MFMA B-operand fragments: lane (r,hh) takes chunk 2ks+hh of row r.
+__device__ __forceinline__ void fetch_q_frags(half8 (&qf)[8], const char* img, int lane) {
+    lane = opaque(lane);
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const half8*>(img + stage_img_off(r, 2 * ks + hh));
+}
+
+// The kernel.  gridDim.x workgroups walk the work items (head, query block) item = blockIdx.x,
+// blockIdx.x + gridDim.x, ...  as ONE stream of K/V tiles: the loads for the next tile are issued
+// before the current tile's math whether that tile belongs to this item or to the next one, the
+// next item's Q rows are fetched right after the current item's last Q.K^T, and an item's output
+// stores drain behind the next item's first tiles.  With gridDim.x == number of items it
+// degenerates to one item per workgroup.
+//
+// The last tile of an item is a separate copy of the tile body: the steady-state loop then carries
+// nothing but the K/V staging registers across its back edge, and every wait on a global load is a
+// counted one (a conditional Q reload inside the loop made the compiler drain all loads, the
+// prefetched tile included, in front of every Q.K^T).
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams p) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int QB = NWAVES * kRowsPerWave;
+    constexpr int CHUNKS = (kTileBytes / 16) / NT;  // 16-byte chunks per thread per tile
+    static_assert(CHUNKS >= 1, "too many threads for one tile");
+
+    // Two separate LDS objects: the K/V ring and the per-wave staging images.  With one array the
+    // compiler must assume that a tile read may alias an in-flight Q transfer into an image and
+    // drains every outstanding load in front of the first read after the transfer was issued.
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) char img_all[NWAVES * kRowsPerWave * kRowBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LaneGeom g = make_lane_geom(lane);
+    char* img = img_all + wave * (kRowsPerWave * kRowBytes);
+
+    // ---- staging geometry: thread t moves 16-byte chunk (t + i*NT) of a tile, i.e. row
+    //      (t>>4) + i*RSTEP, chunk t&15.  RSTEP is a multiple of 16, so the swizzle term is the
+    //      same for every i and the per-i offsets are compile-time constants.
+    constexpr int RSTEP = NT / 16;
+    const int st_row = tid >> 4, st_ch = tid & 15;
+    const int st_goff = st_row * kHeadDim + st_ch * 8;                              // elements
+    const int st_koff = st_row * kRowBytes + ((st_ch ^ (st_row & 15)) << 4);        // bytes in a K buffer
+    const int st_voff = st_row * kRowBytes + ((st_ch ^ ((st_row & 3) << 2)) << 4);  // bytes in a V buffer
+    u32x4 st_k[CHUNKS], st_v[CHUNKS];
+
+#define FA_STAGE_LOAD(kt_, vt_)                                                                 \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < CHUNKS; ++i) {                                    \
+            st_k[i] = *reinterpret_cast<const u32x4*>((kt_) + st_goff + i * RSTEP * kHeadDim);  \
+            st_v[i] = *reinterpret_cast<const u32x4*>((vt_) + st_goff + i * RSTEP * kHeadDim);  \
+        }                                                                                       \
+    } while (0)
+#define FA_STAGE_WRITE(buf)                                                                     \
+    do {                                                                                        \
+        char* kw = smem + (buf) * 2 * kTileBytes;                                               \
+        _Pragma("unroll") for (int i = 0; i < CHUNKS; ++i) {                                    \
+            *reinterpret_cast<u32x4*>(kw + st_koff + i * RSTEP * kRowBytes) = st_k[i];          \
+            *reinterpret_cast<u32x4*>(kw + kTileBytes + st_voff + i * RSTEP * kRowBytes) = st_v[i]; \
+        }                                                                                       \
+    } while (0)
+
+    const int n_items = p.bh * p.q_blocks;
+    const int n_tiles = p.lk / kKvTile;
+    const float c = p.scale_log2e;
+    constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
+
+    // ---- first item
+    int item = blockIdx.x;
+    int head, qb;
+    decode_item(p, item, head, qb);
+    const half_t* kt = p.k + (size_t)head * p.lk * kHeadDim;  // tile being staged
+    const half_t* vt = p.v + (size_t)head * p.lk * kHeadDim;
+    int q_row0 = qb * QB + wave * kRowsPerWave;
+    bool wave_valid = q_row0 < p.lq;                                   // wave-uniform; waves past the last
+    size_t wrow = (size_t)head * p.lq + (wave_valid ? q_row0 : 0);     // row still stage K/V
+    size_t srow = wrow + g.r;
+
+    // Q takes the same route for the first item as for every later one (rows -> staging image ->
+    // fragments), so the fragments are never the destination of a global load and no wait on them
+    // can reach into the tile loop.
+    half8 qf[8];
+    dma_q_rows(p.q + wrow * kHeadDim, img, lane);
+    FA_STAGE_LOAD(kt, vt);
+    FA_STAGE_WRITE(0);
+    f32x16 oacc[4];
+    float m_run, l_run, m_true;
+    init_state(p, srow, g.hh, oacc, m_run, m_true, l_run);
+    __syncthreads();
+    fetch_q_frags(qf, img, lane);
+
+#ifdef FA_STAMPS
+    int n_stamp = 0;
+#define FA_STAMP()                                                                                  \
+    do {                                                                                            \
+        if (p.stamps && tid == 0 && n_stamp < 32)                                                   \
+            p.stamps[(size_t)blockIdx.x * 32 + n_stamp++] = __builtin_amdgcn_s_memrealtime();       \
+    } while (0)
+#else
+#define FA_STAMP() do {} while (0)
+#endif
+    FA_STAMP();
+    int buf = 0;
+    for (;;) {
+        // ---- tiles 0 .. n_tiles-2: the next tile is the next 64 keys of the same head
+        for (int t = 0; t + 1 < n_tiles; ++t) {
+            kt += kTileElems;
+            vt += kTileElems;
+            FA_STAGE_LOAD(kt, vt);
+#ifdef FA_PIN_LOADS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            const char* kb = smem + buf * 2 * kTileBytes;
+            f32x16 s0, s1;
+            half8 pf[4];
+            qk_tile(kb, g, qf, s0, s1);
+            softmax_tile(s0, s1, c, m_run, m_true, l_run, oacc, pf);
+            pv_tile(kb + kTileBytes, g, pf, oacc);
+            FA_STAGE_WRITE(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        FA_STAMP();
+        // ---- last tile of the item: the next tile, if any, is tile 0 of the next item's head
+        const int next_item = item + (int)gridDim.x;
+        const bool more_items = next_item < n_items;
+        int nhead = head, nqb = qb;
+        bool nvalid = wave_valid;
+        size_t nwrow = wrow;
+        if (more_items) {
+            decode_item(p, next_item, nhead, nqb);
+            const int nq_row0 = nqb * QB + wave * kRowsPerWave;
+            nvalid = nq_row0 < p.lq;
+            nwrow = (size_t)nhead * p.lq + (nvalid ? nq_row0 : 0);
+            // the staging image is idle during the tile (the Q fragments are in registers, the output
+            // goes through it only afterwards): start the next item's Q rows towards it now
+            dma_q_rows(p.q + nwrow * kHeadDim, img, lane);
+            kt = p.k + (size_t)nhead * p.lk * kHeadDim;
+            vt = p.v + (size_t)nhead * p.lk * kHeadDim;
+            FA_STAGE_LOAD(kt, vt);
+        }
+        const char* kb = smem + buf * 2 * kTileBytes;
+        f32x16 s0, s1;
+        half8 pf[4];
+        qk_tile(kb, g, qf, s0, s1);
+        softmax_tile(s0, s1, c, m_run, m_true, l_run, oacc, pf);
+        pv_tile(kb + kTileBytes, g, pf, oacc);
+
+        if (more_items) {
+            // waits for the tile loads and, with them, for the older Q transfer; the fragments are
+            // taken out of the image before the output write-out reuses it
+            FA_STAGE_WRITE(buf ^ 1);
+            fetch_q_frags(qf, img, lane);
+        }
+        if (wave_valid) {
+            if (p.flags & kFlagStoreState)
+                finish_rows(p, srow, g.hh, oacc, m_run, m_true, l_run);
+            else
+                store_output_rows(p.o + wrow * kHeadDim, img, lane, oacc, l_run);
+        }
+        FA_STAMP();
+        if (!more_items) break;
+
+        item = next_item;
+        head = nhead;
+        qb = nqb;
+        wave_valid = nvalid;
+        wrow = nwrow;
+        srow = nwrow + g.r;
+        init_state(p, srow, g.hh, oacc, m_run, m_true, l_run);
+        __syncthreads();
+        buf ^= 1;
+        FA_STAMP();
+    }
+}
+
+#undef FA_STAMP
 #undef FA_STAGE_LOAD
 #undef FA_STAGE_WRITE
 

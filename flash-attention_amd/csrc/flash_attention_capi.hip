@@ -34,26 +34,53 @@ int fail(int code, const char* fmt, const char* detail = "") {
         }                                                                                 \
     } while (0)
 
-// Workgroup size.  8 waves (256 query rows) read each K/V tile from L2 half as often per query
-// row and win from L = 2048 up; below that a head has few key tiles, the per-workgroup prologue
-// and epilogue dominate, and two independent 4-wave workgroups per CU overlap them better.
+// Workgroup size.  8 waves (256 query rows, one workgroup per CU) is the regular shape; 4 waves
+// (128 rows) serve sequence lengths that are not a multiple of 256.
 int pick_waves(int bh, int lq, int lk) {
+    (void)bh;
+    (void)lk;
     if (const char* e = std::getenv("FA_NWAVES")) {
         const int n = std::atoi(e);
         if (n == 4 || n == 8) return n;
     }
-    if (lq % 256 != 0 || lk <= 1024) return 4;
-    const long blocks8 = (long)bh * (lq / 256);
-    return blocks8 >= 512 ? 8 : 4;
+    return lq % 256 == 0 ? 8 : 4;
 }
+
+// Compute units of the current device (cached per device id).
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
+    return cached[dev];
+}
+
+#ifdef FA_STAMPS
+unsigned long long* g_stamps = nullptr;
+extern "C" void fa_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
+#endif
 
 int launch(const fa::FwdParams& base, hipStream_t stream) {
     fa::FwdParams p = base;
+#ifdef FA_STAMPS
+    p.stamps = g_stamps;
+#endif
     const int nw = pick_waves(p.bh, p.lq, p.lk);
     const int qb_rows = nw * fa::kRowsPerWave;
     p.q_blocks = (p.lq + qb_rows - 1) / qb_rows;
-    const long grid = (long)p.bh * p.q_blocks;
-    if (grid <= 0 || grid > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
+    const long items = (long)p.bh * p.q_blocks;
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
+    // Resident workgroups: registers admit 8 waves per CU, i.e. one 8-wave or two 4-wave
+    // workgroups.  More items than that are walked by the resident workgroups as one stream.
+    long grid = (long)device_cus();  // LDS admits one workgroup per CU for either size
+    if (const char* e = std::getenv("FA_PERSISTENT"))
+        if (std::atoi(e) == 0) grid = items;
+    if (grid > items) grid = items;
+    // static LDS: the K/V ring (64 KiB) plus one 8 KiB staging image per wave = 128 KiB / 96 KiB
     if (nw == 8)
         hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
     else
