@@ -132,7 +132,13 @@ __device__ __forceinline__ void load_q_frags(half8 (&qf)[8], const half_t* q_row
 #endif
 }
 
-// S^T = K.Q^T : two 32-key blocks, 8 k-steps of 16 over D
+// S^T = K.Q^T : two 32-key blocks, 8 k-steps of 16 over D.  The K fragments run FA_K_AHEAD k-steps
+// ahead of the MFMAs that consume them (left alone the compiler reads each pair right before its
+// use and every MFMA pair waits out a full LDS round trip); the sched_group_barrier sequence pins
+// that order.
+#ifndef FA_K_AHEAD
+#define FA_K_AHEAD 4
+#endif
 __device__ __forceinline__ void qk_tile(const char* kb, const LaneGeom& g, const half8 (&qf)[8], f32x16& s0,
                                         f32x16& s1) {
 #pragma unroll
@@ -140,13 +146,29 @@ __device__ __forceinline__ void qk_tile(const char* kb, const LaneGeom& g, const
         s0[e] = 0.0f;
         s1[e] = 0.0f;
     }
+    half8 ka0[FA_K_AHEAD], ka1[FA_K_AHEAD];
+#pragma unroll
+    for (int i = 0; i < FA_K_AHEAD; ++i) {
+        ka0[i] = *reinterpret_cast<const half8*>(kb + g.k_rd[i]);
+        ka1[i] = *reinterpret_cast<const half8*>(kb + g.k_rd[i] + 32 * kRowBytes);
+    }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const half8 ka0 = *reinterpret_cast<const half8*>(kb + g.k_rd[ks]);
-        const half8 ka1 = *reinterpret_cast<const half8*>(kb + g.k_rd[ks] + 32 * kRowBytes);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka0, qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1, qf[ks], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka0[ks % FA_K_AHEAD], qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1[ks % FA_K_AHEAD], qf[ks], s1, 0, 0, 0);
+        if (ks + FA_K_AHEAD < 8) {
+            ka0[ks % FA_K_AHEAD] = *reinterpret_cast<const half8*>(kb + g.k_rd[ks + FA_K_AHEAD]);
+            ka1[ks % FA_K_AHEAD] = *reinterpret_cast<const half8*>(kb + g.k_rd[ks + FA_K_AHEAD] + 32 * kRowBytes);
+        }
     }
+#ifndef FA_NO_SCHED_HINTS
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * FA_K_AHEAD, 0);  // DS_READ
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+        if (ks + FA_K_AHEAD < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+#endif
 }
 
 // Online softmax for query (lane & 31); this lane holds 32 of the tile's 64 keys.  The running
@@ -309,6 +331,9 @@ __device__ __forceinline__ int opaque(int x) {
 }
 
 // O = acc / l as fp16, written through the staging image so that global stores are whole rows.
+// All eight row-wise reads are issued before the first store (the accumulators are dead by then, so
+// registers are plentiful); addresses are one base plus immediates: (4i+row0)&15 = 4(i&3) + row0, so
+// the swizzled chunk of read i is (ch ^ row0) ^ 4(i&3).
 __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
                                                   float l_run) {
     const float inv = 1.0f / half_wave_sum(l_run);
@@ -325,14 +350,20 @@ __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int
             *reinterpret_cast<half4*>(img + stage_img_off(r, 4 * db + g4) + 8 * hh) = __builtin_convertvector(t, half4);
         }
     const int row0 = lane >> 4, ch = lane & 15;
+    const char* rd = img + row0 * kRowBytes;
+    int sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw[j] = ((ch ^ row0) ^ (4 * j)) << 4;
+    u32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4*>(rd + i * 4 * kRowBytes + sw[i & 3]);
+    half_t* wr = o_rows + row0 * kHeadDim + ch * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + row0;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(img + stage_img_off(row, ch));
 #ifdef FA_ABLATE_NO_STORE
-        asm volatile("" ::"v"(v));
+        asm volatile("" ::"v"(v[i]));
 #else
-        *reinterpret_cast<u32x4*>(o_rows + row * kHeadDim + ch * 8) = v;
+        *reinterpret_cast<u32x4*>(wr + i * 4 * kHeadDim) = v[i];
 #endif
     }
 }
@@ -425,8 +456,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
     int item = blockIdx.x;
     int head, qb;
     decode_item(p, item, head, qb);
-    const half_t* kt = p.k + (size_t)head * p.lk * kHeadDim;  // tile being staged
-    const half_t* vt = p.v + (size_t)head * p.lk * kHeadDim;
+#ifdef FA_ABLATE_SAME_KV
+#define FA_KV_HEAD(h) ((h) & 7)
+#else
+#define FA_KV_HEAD(h) (h)
+#endif
+    const half_t* kt = p.k + (size_t)FA_KV_HEAD(head) * p.lk * kHeadDim;  // tile being staged
+    const half_t* vt = p.v + (size_t)FA_KV_HEAD(head) * p.lk * kHeadDim;
     int q_row0 = qb * QB + wave * kRowsPerWave;
     bool wave_valid = q_row0 < p.lq;                                   // wave-uniform; waves past the last
     size_t wrow = (size_t)head * p.lq + (wave_valid ? q_row0 : 0);     // row still stage K/V
@@ -440,8 +476,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
     FA_STAGE_LOAD(kt, vt);
     FA_STAGE_WRITE(0);
     f32x16 oacc[4];
-    float m_run, l_run, m_true;
-    init_state(p, srow, g.hh, oacc, m_run, m_true, l_run);
+    float m_run = 0.f, l_run = 1.f, m_true = 0.f;  // set per item by init_state
     __syncthreads();
     fetch_q_frags(qf, img, lane);
 
@@ -449,32 +484,87 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
     int n_stamp = 0;
 #define FA_STAMP()                                                                                  \
     do {                                                                                            \
-        if (p.stamps && tid == 0 && n_stamp < 32)                                                   \
-            p.stamps[(size_t)blockIdx.x * 32 + n_stamp++] = __builtin_amdgcn_s_memrealtime();       \
+        if (p.stamps && tid == 0 && n_stamp < 60)                                                   \
+            p.stamps[(size_t)blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();       \
+        if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memtime(); \
+        if (p.stamps && tid == 0 && n_stamp == 1) p.stamps[(size_t)blockIdx.x * 64 + 62] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define FA_STAMP() do {} while (0)
 #endif
     FA_STAMP();
     int buf = 0;
+    // Output of the item just finished, still in the accumulators: it is written out under the
+    // first Q.K^T of the next item (vector/LDS/store work beside matrix work) rather than between
+    // the two items.
+    bool out_pending = false, out_valid = false;
+    size_t out_wrow = 0;
+
+#define FA_WRITE_OUT()                                                                         \
+    do {                                                                                       \
+        if (p.flags & kFlagStoreState)                                                         \
+            finish_rows(p, out_wrow + g.r, g.hh, oacc, m_run, m_true, l_run);                  \
+        else                                                                                   \
+            store_output_rows(p.o + out_wrow * kHeadDim, img, lane, oacc, l_run);              \
+    } while (0)
+#define FA_TILE(kb_)                                                                           \
+    do {                                                                                       \
+        f32x16 s0, s1;                                                                         \
+        half8 pf[4];                                                                           \
+        qk_tile((kb_), g, qf, s0, s1);                                                         \
+        softmax_tile(s0, s1, c, m_run, m_true, l_run, oacc, pf);                               \
+        FA_MID_BARRIER();                                                                      \
+        pv_tile((kb_) + kTileBytes, g, pf, oacc);                                              \
+    } while (0)
+
+#ifdef FA_HACK_STAGGER
+#define FA_MID_BARRIER() __syncthreads()
+    if (wave >= NWAVES / 2) __syncthreads();
+#else
+#define FA_MID_BARRIER() do {} while (0)
+#endif
     for (;;) {
-        // ---- tiles 0 .. n_tiles-2: the next tile is the next 64 keys of the same head
-        for (int t = 0; t + 1 < n_tiles; ++t) {
+        if (n_tiles > 1) {
+            // ---- tile 0 of the item, with the previous item's write-out folded in
             kt += kTileElems;
             vt += kTileElems;
             FA_STAGE_LOAD(kt, vt);
-#ifdef FA_PIN_LOADS
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            const char* kb = smem + buf * 2 * kTileBytes;
-            f32x16 s0, s1;
-            half8 pf[4];
-            qk_tile(kb, g, qf, s0, s1);
-            softmax_tile(s0, s1, c, m_run, m_true, l_run, oacc, pf);
-            pv_tile(kb + kTileBytes, g, pf, oacc);
+            {
+                const char* kb = smem + buf * 2 * kTileBytes;
+                f32x16 s0, s1;
+                half8 pf[4];
+                // (the tile's Q.K^T is spelled out in both branches so that the write-out shares a
+                // basic block with its MFMAs and can be scheduled between them)
+                if (out_pending && out_valid) {
+                    qk_tile(kb, g, qf, s0, s1);
+                    FA_WRITE_OUT();
+                } else {
+                    qk_tile(kb, g, qf, s0, s1);
+                }
+                init_state(p, srow, g.hh, oacc, m_run, m_true, l_run);
+                softmax_tile(s0, s1, c, m_run, m_true, l_run, oacc, pf);
+                FA_MID_BARRIER();
+                pv_tile(kb + kTileBytes, g, pf, oacc);
+            }
             FA_STAGE_WRITE(buf ^ 1);
             __syncthreads();
             buf ^= 1;
+            FA_STAMP();
+
+            // ---- tiles 1 .. n_tiles-2: the next tile is the next 64 keys of the same head
+            for (int t = 1; t + 1 < n_tiles; ++t) {
+                kt += kTileElems;
+                vt += kTileElems;
+                FA_STAGE_LOAD(kt, vt);
+                FA_TILE(smem + buf * 2 * kTileBytes);
+                FA_STAGE_WRITE(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+                FA_STAMP();
+            }
+        } else {
+            if (out_pending && out_valid) FA_WRITE_OUT();
+            init_state(p, srow, g.hh, oacc, m_run, m_true, l_run);
         }
 
         FA_STAMP();
@@ -492,31 +582,28 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
             // the staging image is idle during the tile (the Q fragments are in registers, the output
             // goes through it only afterwards): start the next item's Q rows towards it now
             dma_q_rows(p.q + nwrow * kHeadDim, img, lane);
-            kt = p.k + (size_t)nhead * p.lk * kHeadDim;
-            vt = p.v + (size_t)nhead * p.lk * kHeadDim;
+            kt = p.k + (size_t)FA_KV_HEAD(nhead) * p.lk * kHeadDim;
+            vt = p.v + (size_t)FA_KV_HEAD(nhead) * p.lk * kHeadDim;
             FA_STAGE_LOAD(kt, vt);
         }
-        const char* kb = smem + buf * 2 * kTileBytes;
-        f32x16 s0, s1;
-        half8 pf[4];
-        qk_tile(kb, g, qf, s0, s1);
-        softmax_tile(s0, s1, c, m_run, m_true, l_run, oacc, pf);
-        pv_tile(kb + kTileBytes, g, pf, oacc);
-
-        if (more_items) {
-            // waits for the tile loads and, with them, for the older Q transfer; the fragments are
-            // taken out of the image before the output write-out reuses it
-            FA_STAGE_WRITE(buf ^ 1);
-            fetch_q_frags(qf, img, lane);
-        }
-        if (wave_valid) {
-            if (p.flags & kFlagStoreState)
-                finish_rows(p, srow, g.hh, oacc, m_run, m_true, l_run);
-            else
-                store_output_rows(p.o + wrow * kHeadDim, img, lane, oacc, l_run);
-        }
+        FA_TILE(smem + buf * 2 * kTileBytes);
         FA_STAMP();
-        if (!more_items) break;
+
+        out_pending = true;
+        out_valid = wave_valid;
+        out_wrow = wrow;
+        if (!more_items) {
+            if (out_valid) FA_WRITE_OUT();
+#ifdef FA_HACK_STAGGER
+            if (wave < NWAVES / 2) __syncthreads();
+#endif
+            break;
+        }
+        // waits for the tile loads and, with them, for the older Q transfer; the fragments leave the
+        // image before the write-out (in the next tile) reuses it
+        FA_STAGE_WRITE(buf ^ 1);
+        fetch_q_frags(qf, img, lane);
+        FA_STAMP();
 
         item = next_item;
         head = nhead;
@@ -524,14 +611,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
         wave_valid = nvalid;
         wrow = nwrow;
         srow = nwrow + g.r;
-        init_state(p, srow, g.hh, oacc, m_run, m_true, l_run);
         __syncthreads();
         buf ^= 1;
         FA_STAMP();
     }
 }
 
+#undef FA_WRITE_OUT
+#undef FA_MID_BARRIER
+#undef FA_TILE
 #undef FA_STAMP
+#undef FA_KV_HEAD
 #undef FA_STAGE_LOAD
 #undef FA_STAGE_WRITE
 

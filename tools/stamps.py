@@ -17,7 +17,7 @@ H, D = 16, 128
 n = 16384 * H * D
 q = torch.empty(n, dtype=torch.float16, device=dev); k = torch.empty_like(q); v = torch.empty_like(q); o = torch.empty_like(q)
 fa.init_half(q, 1234); fa.init_half(k, 2345); fa.init_half(v, 3456)
-stamps = torch.zeros(256 * 32, dtype=torch.int64, device=dev)
+stamps = torch.zeros(256 * 64, dtype=torch.int64, device=dev)
 p = lambda t: ct.cast(ct.c_void_p(t.data_ptr()), fa.HalfPtr)
 for L in [int(x) for x in sys.argv[1:]] or [512, 1024, 2048]:
     B = 16384 // L
@@ -29,12 +29,17 @@ for L in [int(x) for x in sys.argv[1:]] or [512, 1024, 2048]:
     L_.fa_debug_set_stamps(ct.c_void_p(stamps.data_ptr()))
     L_.fa_forward(p(q), p(k), p(v), p(o), B, H, L, D, 64, None, None)
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(256, 32).astype(np.float64) / 100.0  # us
-    nst = int((s[0] > 0).sum())
+    raw = stamps.cpu().numpy().reshape(256, 64).astype(np.float64)
+    s = raw / 100.0  # us
+    nst = int((s[0, :60] > 0).sum())
+    dt_real = raw[:, nst - 1] - raw[:, 0]
+    dt_clk = raw[:, 63] - raw[:, 62]
+    print(f"    shader clock during the kernel: median {np.median(dt_clk / dt_real * 100):.0f} MHz")
     t0 = s[:, 0].min()
     rel = s[:, :nst] - t0
     print(f"--- L={L}: {nst} stamps per workgroup; kernel span {rel.max():.1f} us; start spread {rel[:,0].max():.2f} us")
-    names = ["start"] + sum([[f"it{i}:tiles_done", f"it{i}:out_issued", f"it{i}:next_ready"] for i in range(8)], [])
+    names = [str(i) for i in range(64)]
+    names_old = ["start"] + sum([[f"it{i}:tiles_done", f"it{i}:last_pv_done", f"it{i}:staged+qfetch", f"it{i}:out_issued", f"it{i}:next_ready"] for i in range(8)], [])
     prev = rel[:, 0]
     for j in range(1, nst):
         d = rel[:, j] - rel[:, j - 1]
