@@ -33,6 +33,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP's uint4 is a struct
 
@@ -179,10 +180,21 @@ __device__ __forceinline__ void qk_tile(const char* kb, const LaneGeom& g, const
 // key 16s + 8(j>>2) + 4hh + (j&3).
 __device__ __forceinline__ void softmax_tile(f32x16& s0, f32x16& s1, float c, float& m_run, float& m_true,
                                              float& l_run, f32x16 (&oacc)[4], half8 (&pf)[4]) {
-    float mx = fmaxf(s0[0], s1[0]);
+#ifdef FA_ABLATE_SOFTMAX  // timing experiments only: wrong results
+    pf[0] = pack_half8(s0, 0);
+    pf[1] = pack_half8(s0, 8);
+    pf[2] = pack_half8(s1, 0);
+    pf[3] = pack_half8(s1, 8);
+    return;
+#endif
+    // two chains of max(max(a, x), y), each link one v_max3_f32
+    float mx0 = fmaxf(s0[0], s0[1]), mx1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
-    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
-    mx = half_wave_max(mx) * c;
+    for (int e = 2; e < 16; e += 2) {
+        mx0 = fmaxf(fmaxf(mx0, s0[e]), s0[e + 1]);
+        mx1 = fmaxf(fmaxf(mx1, s1[e]), s1[e + 1]);
+    }
+    const float mx = half_wave_max(fmaxf(mx0, mx1)) * c;
     m_true = fmaxf(m_true, mx);
     if (!__all(mx - m_run <= kRescaleSlack)) {
         const float m_new = fmaxf(m_run, mx);
@@ -194,14 +206,27 @@ __device__ __forceinline__ void softmax_tile(f32x16& s0, f32x16& s1, float c, fl
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
     }
-    float rowsum = 0.0f;
+    // score*c - m and the row sum go through the packed fp32 forms (v_pk_fma_f32, v_pk_add_f32):
+    // two elements per instruction
+    const f32x2 c2 = {c, c}, nm2 = {-m_run, -m_run};
+    f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], c, -m_run));
-        s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, -m_run));
-        rowsum += s0[e] + s1[e];
+    for (int e = 0; e < 16; e += 2) {
+        f32x2 a = {s0[e], s0[e + 1]}, b = {s1[e], s1[e + 1]};
+        a = __builtin_elementwise_fma(a, c2, nm2);
+        b = __builtin_elementwise_fma(b, c2, nm2);
+        a[0] = __builtin_amdgcn_exp2f(a[0]);
+        a[1] = __builtin_amdgcn_exp2f(a[1]);
+        b[0] = __builtin_amdgcn_exp2f(b[0]);
+        b[1] = __builtin_amdgcn_exp2f(b[1]);
+        sum2 += a;
+        sum2 += b;
+        s0[e] = a[0];
+        s0[e + 1] = a[1];
+        s1[e] = b[0];
+        s1[e + 1] = b[1];
     }
-    l_run += rowsum;
+    l_run += sum2[0] + sum2[1];
     pf[0] = pack_half8(s0, 0);
     pf[1] = pack_half8(s0, 8);
     pf[2] = pack_half8(s1, 0);
@@ -493,6 +518,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams 
 #define FA_STAMP() do {} while (0)
 #endif
     FA_STAMP();
+#ifdef FA_PRIO_SKEW
+    // waves w and w + NWAVES/2 share a SIMD: a fixed priority difference lets one run ahead, so that
+    // its softmax falls under the other's MFMAs instead of both doing the same kind of work at once
+    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(FA_PRIO_SKEW);
+#endif
     int buf = 0;
     // Output of the item just finished, still in the accumulators: it is written out under the
     // first Q.K^T of the next item (vector/LDS/store work beside matrix work) rather than between
