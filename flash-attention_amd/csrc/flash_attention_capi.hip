@@ -14,7 +14,7 @@
 #include <string>
 
 #include "fa_fwd_kernel.hpp"
-#include "fa_fwd_pp_kernel.hpp"
+#include "fa_fwd_ring_kernel.hpp"
 
 namespace {
 
@@ -81,11 +81,12 @@ int launch(const fa::FwdParams& base, hipStream_t stream) {
     if (const char* e = std::getenv("FA_PERSISTENT"))
         if (std::atoi(e) == 0) grid = items;
     if (grid > items) grid = items;
-    // static LDS: the K/V ring (64 KiB) plus one 8 KiB staging image per wave = 128 KiB / 96 KiB
-    bool pingpong = false;
-    if (const char* e = std::getenv("FA_PP")) pingpong = std::atoi(e) != 0;
-    if (nw == 8 && pingpong)
-        hipLaunchKernelGGL(fa::fa_fwd_pp_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+    // static LDS: ring kernel 96 KiB ring + 64 KiB staging images; register-staged kernel 64 KiB ring
+    // + 8 KiB staging image per wave
+    bool ring = true;
+    if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
+    if (nw == 8 && ring)
+        hipLaunchKernelGGL(fa::fa_fwd_ring_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
     else if (nw == 8)
         hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
     else
