@@ -263,6 +263,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
             out_wrow = wrow;
             if (!more_items) {
                 if (out_valid) RING_WRITE_OUT();
+                wait_all_vmem();  // the last step's (redundant) transfer must not outlive the workgroup's LDS
                 break;
             }
         }

@@ -1,0 +1,696 @@
+// Forward kernel with ONE wave per SIMD: 4 waves per workgroup, 64 query rows per wave, the whole
+// 512-entry register file per lane.
+//
+// With two waves on a SIMD (fa_fwd_kernel, fa_fwd_ring_kernel) the matrix pipe idles while both do
+// softmax and the vector ALU idles while both issue MFMAs; alternating their phases with barriers
+// buys little, because every phase change costs a barrier, an LDS prologue and an arbitration
+// fight.  Here the two things that should overlap live in ONE instruction stream.  A wave's 64 rows
+// are two 32-row sub-blocks A and B, each with its own Q fragments, S^T tile, P^T fragments, O^T
+// accumulator and running state, and B runs half a tile behind A:
+//
+//     phase 1 of step t :  MFMA  S_B(t)   = K(t).Q_B^T ,  O_B += V(t-1)^T.P_B(t-1)^T
+//                          VALU  P_A(t)   = exp2(S_A(t).c - m_A),  l_A += rowsum
+//                          then  mx_B = rowmax S_B(t), rescale decision for B
+//     phase 2 of step t :  MFMA  S_A(t+1) = K(t+1).Q_A^T , O_A += V(t)^T.P_A(t)^T
+//                          VALU  P_B(t)   = exp2(S_B(t).c - m_B),  l_B += rowsum
+//                          then  mx_A = rowmax S_A(t+1), rescale decision for A
+//
+// Each phase is one basic block of 32 MFMAs with the other sub-block's exponentials, the row-max
+// chain of the scores just produced and the LDS operand reads placed in the gaps between them
+// (sched_group_barrier pins the interleave; an MFMA holds the SIMD's vector issue for only 8 of its
+// 32 cycles).  The rescale decision is the only branch and sits between the blocks, where no MFMA
+// is writing the accumulator.
+//
+// K therefore runs one tile ahead of V.  LDS: a K ring and a V ring of three 16 KiB slots each, both
+// filled by DMA (global_load_lds, hidden from the compiler as in fa_fwd_ring_kernel).  In step t the
+// waves read K(t), K(t+1), V(t-1), V(t); K(t+2) and V(t+1) are in flight into the slots of K(t-1)
+// and V(t-2), whose last readers finished before the barrier that ended step t-1.  One barrier per
+// step, at its end, after each wave has waited for its own DMA.  The first K fragments of the next
+// phase are always read at the end of the current one (they were published at least one barrier
+// earlier), so no phase opens with an exposed LDS round trip.
+//
+// Items (head, 256-row query block) form one stream of tiles per workgroup, as in the other
+// kernels.  The next item's Q rows are DMAed into the wave's 16 KiB staging image during the item's
+// last-but-one step; A picks its fragments up before phase 2 of the last step (which already
+// computes S_A of the next item), B before phase 1 of the next step.  A sub-block's output is
+// written out (through its half of the image, as whole rows) right after the phase that finished
+// it.  The kernel needs lq % 256 == 0 and at least 3 tiles per item; the launcher sends other
+// shapes to the other kernels.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "fa_fwd_ring_kernel.hpp"
+
+namespace fa {
+
+#ifndef W64_K_AHEAD
+#define W64_K_AHEAD 2
+#endif
+#ifndef W64_V_AHEAD
+#define W64_V_AHEAD 4
+#endif
+
+struct RowState {
+    float m_run, m_true, l_run;
+};
+
+// LDS-DMA of one 1 KiB piece with the LDS base already in m0: lane l fills bytes 16l..16l+15 at
+// m0 + OFS with the 16 bytes at base + off + OFS (the instruction offset applies to both sides).
+// m0 is left changed: nothing else in this kernel uses it.
+__device__ __forceinline__ void dma_set_base(unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_addr) : "memory");
+}
+template <int OFS>
+__device__ __forceinline__ void dma_piece_at(const half_t* base, unsigned off_bytes) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(off_bytes), "s"(base), "n"(OFS) : "memory");
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ...
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// The O^T accumulators are OWNED by the inline asm below: sub-block A in a[0:63], sub-block B in
+// a[64:127] (block db of 32 output columns in 16 consecutive registers); so are the Q fragments
+// (a[128:191]), which an MFMA can take as its B operand from there.  They are named literally
+// in the instruction strings and are not C++ values, so the compiler cannot move, copy or re-home
+// them (as a value, an accumulator that is also read by ordinary vector code somewhere in the loop
+// is kept in architectural registers and copied in and out around every MFMA).  The kernel keeps
+// its own register demand under 256, so the compiler has no use for accumulator registers; one
+// statement with the whole range in its clobber list makes the kernel descriptor allocate them.
+// Every statement that touches them is volatile: program order is the only ordering there is.
+//
+// The compiler does not know these statements are MFMAs and inserts no wait states for them:
+//   * a register an MFMA wrote is read by other instructions only several MFMAs later (the phase
+//     below is ordered that way) or behind acc_fence();
+//   * their operands are LDS read results (the compiler's s_waitcnt covers those) or registers
+//     written by vector instructions at least a few instructions earlier.
+// ---------------------------------------------------------------------------------------------
+constexpr int kAccA = 0, kAccB = 64;     // O^T of sub-blocks A and B
+constexpr int kQregA = 128, kQregB = 160;  // their Q fragments: k-step ks in a[base + 4ks : base + 4ks + 3]
+
+__device__ __forceinline__ void acc_reserve() {
+    asm volatile(""
+                 :
+                 :
+                 :
+                   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14",
+                   "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28",
+                   "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42",
+                   "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56",
+                   "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70",
+                   "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84",
+                   "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98",
+                   "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110",
+                   "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122",
+                   "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134",
+                   "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146",
+                   "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158",
+                   "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170",
+                   "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182",
+                   "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+}
+// S (architectural registers): d = a.q  /  d += a.q, with q = a[QLO:QLO+3]
+template <int QLO>
+__device__ __forceinline__ void mfma_s_first(f32x16& d, const half8& a) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], 0" : "=&v"(d) : "v"(a), "n"(QLO), "n"(QLO + 3));
+}
+template <int QLO>
+__device__ __forceinline__ void mfma_s(f32x16& d, const half8& a) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], %0" : "+v"(d) : "v"(a), "n"(QLO), "n"(QLO + 3));
+}
+// O: a[LO:LO+15] += a.b
+template <int LO>
+__device__ __forceinline__ void mfma_acc(const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]"
+                 :
+                 : "v"(a), "v"(b), "n"(LO), "n"(LO + 15));
+}
+// Wait states between the last MFMA on an accumulator and a v_accvgpr_read of it.
+__device__ __forceinline__ void acc_fence() { asm volatile("s_nop 15\n\ts_nop 3"); }
+template <int R>
+__device__ __forceinline__ float acc_get() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ void acc_put(float x) {
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(x), "n"(R));
+}
+template <int R>
+__device__ __forceinline__ void acc_put_u32(unsigned x) {
+    asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(x), "n"(R));
+}
+// Q fragments of one sub-block: staging image -> registers -> a[QBASE : QBASE+31].  The trailing
+// s_nop separates the last write from an MFMA that reads it.
+template <int QBASE>
+__device__ __forceinline__ void q_install(const char* img_half, int lane) {
+    half8 qf[8];
+    fetch_q_frags(qf, img_half, lane);
+    static_for<32>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const u32x4 wds = __builtin_bit_cast(u32x4, qf[i >> 2]);
+        acc_put_u32<QBASE + i>(wds[i & 3]);
+    });
+    asm volatile("s_nop 3");
+}
+// whole sub-block accumulator <-> values (item boundaries only)
+template <int BASE>
+__device__ __forceinline__ void acc_load(f32x16 (&o)[4]) {
+    acc_fence();
+    static_for<64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        o[i >> 4][i & 15] = acc_get<BASE + i>();
+    });
+}
+template <int BASE>
+__device__ __forceinline__ void acc_store(const f32x16 (&o)[4]) {
+    static_for<64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        acc_put<BASE + i>(o[i >> 4][i & 15]);
+    });
+}
+template <int BASE>
+__device__ __forceinline__ void acc_scale(float alpha) {
+    acc_fence();
+    static_for<64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        acc_put<BASE + i>(acc_get<BASE + i>() * alpha);
+    });
+}
+
+// The rescale decision of fa::softmax_tile, for scores whose scaled row max mx is already known.
+// Runs between two phases: no MFMA is in flight on the accumulator.
+// need: some row's max runs ahead of its reference by more than the slack.
+// (a lane mask: the rows concerned)
+typedef unsigned long long lane_mask_t;
+__device__ __forceinline__ lane_mask_t rescale_needed(float mx, float m_run) {
+    return __builtin_amdgcn_ballot_w64(!(mx - m_run <= kRescaleSlack));
+}
+template <int BASE>
+__device__ __forceinline__ void rescale_if_needed(lane_mask_t need, float mx, RowState& st) {
+    st.m_true = fmaxf(st.m_true, mx);
+    if (need) {
+        const float m_new = fmaxf(st.m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
+        st.m_run = m_new;
+        st.l_run *= alpha;
+        acc_scale<BASE>(alpha);
+    }
+}
+
+// Operand reads with the ring slot folded into the instruction's immediate offset: the per-lane
+// parts of the addresses (W64Geom, absolute LDS byte addresses including the ring's base) never
+// change, and the tile loop is unrolled over the three slots so that every slot offset is a
+// compile-time constant.  No address arithmetic is left in the loop.
+struct W64Geom {
+    unsigned k_ad[8];  // K ring base + lane part of the fragment of k-step ks, key block 0 (block 1: + 32 rows)
+    unsigned v_ad[4];  // V ring base + lane part of the transposed fragment of output block db
+};
+typedef const __attribute__((address_space(3))) half8* lds_half8_ptr;
+typedef __attribute__((address_space(3))) short4_t* lds_short4_ptr;
+// Passing the addresses through an empty asm at the top of a phase keeps "address + slot offset"
+// from being hoisted out of the tile loop as three dozen separate registers: the sum is then
+// formed where it is used, i.e. folded into the read's immediate offset.
+__device__ __forceinline__ void launder(W64Geom& r) {
+    asm volatile(""
+                 : "+v"(r.k_ad[0]), "+v"(r.k_ad[1]), "+v"(r.k_ad[2]), "+v"(r.k_ad[3]), "+v"(r.k_ad[4]), "+v"(r.k_ad[5]),
+                   "+v"(r.k_ad[6]), "+v"(r.k_ad[7]), "+v"(r.v_ad[0]), "+v"(r.v_ad[1]), "+v"(r.v_ad[2]), "+v"(r.v_ad[3]));
+}
+template <int OFS>
+__device__ __forceinline__ half8 read_k_at(const W64Geom& w, int ks, int blk) {
+    return *(lds_half8_ptr)(w.k_ad[ks] + (unsigned)(OFS + blk * 32 * kRowBytes));
+}
+template <int OFS>
+__device__ __forceinline__ half8 read_v_at(const W64Geom& w, int kk, int db) {
+    const unsigned a0 = w.v_ad[db] + (unsigned)(OFS + kk * 16 * kRowBytes);
+    const short4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
+    const short4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 8 * kRowBytes));
+    return __builtin_bit_cast(half8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// One phase (see the file comment), written out gap by gap: 32 MFMAs, and after each of them the
+// LDS reads and the slice of vector work that share its 32 cycles; sched_barrier(0) after every gap
+// keeps the compiler from re-ordering across gaps.  X is the sub-block on the matrix side
+// (accumulator base XACC), Y the one on the vector side.
+//   KB       K slot (byte offset in the K ring) for S_X = K.Q_X^T;  ka0/ka1: its first W64_K_AHEAD
+//            k-steps, already read
+//   VB       V slot for O_X += V^T.P_X^T
+//   KB_NEXT  K slot of the NEXT phase: its first k-steps are read into ka0/ka1 in the last gaps
+//   sx0/sx1  out: S_X                          mx_x     out: scaled row max of S_X
+//   m_x      X's running reference max         need_x   out: rescale_needed(mx_x, m_x)
+//   sy0/sy1  in: S_Y (overwritten by p)        py       out: P_Y fragments;   l_y += row sum
+// Gaps 0-15 are S_X (k-step g/2, key block g&1), gaps 16-31 O_X (V fragment g-16).  The row max of
+// S_X starts in gap 19, three MFMAs after the last one that wrote S_X.
+//   dma(j)   issues piece j (0..7) of the step's tile transfers (j is an integral_constant); called in
+//            gaps 2, 6, 10, ... 30
+template <int XACC, int QBASE, int KB, int VB, int KB_NEXT, typename DMA>
+__device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&ka0)[W64_K_AHEAD],
+                                            half8 (&ka1)[W64_K_AHEAD], f32x16& sx0, f32x16& sx1,
+                                            const half8 (&px)[4], float& mx_x, float m_x, lane_mask_t& need_x, f32x16& sy0,
+                                            f32x16& sy1, float m_y, float& l_y, half8 (&py)[4], float c, DMA&& dma) {
+    constexpr int KA = W64_K_AHEAD, VA = W64_V_AHEAD;
+    static_assert(KA >= 1 && KA <= 4 && (VA == 2 || VA == 4 || VA == 6 || VA == 8), "ring depths");
+    launder(w);
+    half8 ring[VA];
+#ifdef W64_ABLATE_VREAD
+#pragma unroll
+    for (int i = 0; i < VA; ++i) ring[i] = ka0[0];
+#endif
+    const float nm = -m_y;
+    float sum = 0.0f;
+    float a0 = 0.0f, a1 = 0.0f;
+    u32x4 pw[4];
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#define W64_Y(e_) (((e_) < 16) ? sy0[(e_) & 15] : sy1[(e_) & 15])
+    static_for<32>([&](auto ic) {
+        constexpr int gi = decltype(ic)::value;
+        // ---- the MFMA
+        if constexpr (gi < 16) {
+            constexpr int ks = gi >> 1;
+            if constexpr (gi == 0)
+                mfma_s_first<QBASE>(sx0, ka0[0]);
+            else if constexpr (gi == 1)
+                mfma_s_first<QBASE>(sx1, ka1[0]);
+            else if constexpr (gi & 1)
+                mfma_s<QBASE + 4 * ks>(sx1, ka1[ks % KA]);
+            else
+                mfma_s<QBASE + 4 * ks>(sx0, ka0[ks % KA]);
+        } else {
+            constexpr int i = gi - 16;
+            mfma_acc<XACC + 16 * (i & 3)>(ring[i % VA], px[i >> 2]);
+        }
+        // ---- this gap's share of the tile transfer
+        if constexpr ((gi & 3) == 2) dma(std::integral_constant<int, (gi >> 2)>{});
+        // ---- LDS reads
+#ifndef W64_ABLATE_KREAD
+        if constexpr (gi < 16 && (gi & 1)) {  // both MFMAs of k-step gi/2 have taken their fragments
+            constexpr int ks = gi >> 1;
+            if constexpr (ks + KA < 8) {  // key block 1 first: one wait, before the block-0 MFMA, covers both
+                ka1[ks % KA] = read_k_at<KB>(w, ks + KA, 1);
+                ka0[ks % KA] = read_k_at<KB>(w, ks + KA, 0);
+            }
+        }
+#endif
+#ifndef W64_ABLATE_VREAD
+        // V fragments in pairs, the later-used one first, every other gap
+        if constexpr (gi >= 16 - VA && gi < 16 && ((gi - (16 - VA)) & 1) == 0) {
+            constexpr int i = gi - (16 - VA);
+            ring[i + 1] = read_v_at<VB>(w, (i + 1) >> 2, (i + 1) & 3);
+            ring[i] = read_v_at<VB>(w, i >> 2, i & 3);
+        }
+        if constexpr (gi >= 16 && ((gi - 16) & 1) == 1 && gi - 16 - 1 + VA < 16) {
+            constexpr int i = gi - 16 - 1 + VA;  // MFMAs gi-1 and gi have taken fragments i-VA, i-VA+1
+            ring[(i + 1) % VA] = read_v_at<VB>(w, (i + 1) >> 2, (i + 1) & 3);
+            ring[i % VA] = read_v_at<VB>(w, i >> 2, i & 3);
+        }
+#endif
+#ifndef W64_ABLATE_KREAD
+        if constexpr (gi >= 32 - KA) {
+            constexpr int j = gi - (32 - KA);
+            ka1[j] = read_k_at<KB_NEXT>(w, j, 1);
+            ka0[j] = read_k_at<KB_NEXT>(w, j, 0);
+        }
+#endif
+        // ---- vector slice: Y's 32 scores, two per gap in gaps 0-3 and one per gap in gaps 4-27 (so that
+        //      the whole slice is finished inside the phase); each element is summed one gap after
+        //      its exponential, each pair rounded to fp16 one gap after that
+        {
+            constexpr int n_done = (gi < 4) ? 2 * gi : ((gi < 28) ? gi + 4 : 32);          // elements started before this gap
+            constexpr int n_new = (gi < 4) ? 2 : ((gi < 28) ? 1 : 0);                        // started in this gap
+            constexpr int n_prev = (gi == 0) ? 0 : ((gi - 1 < 4) ? 2 * (gi - 1) : ((gi - 1 < 28) ? gi + 3 : 32));
+#ifndef W64_ABLATE_VEC  // (timing experiments only: wrong results)
+            static_for<n_new>([&](auto jc) {
+                constexpr int e = n_done + decltype(jc)::value;
+                if constexpr (e < 16)
+                    sy0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sy0[e], c, nm));
+                else
+                    sy1[e - 16] = __builtin_amdgcn_exp2f(__builtin_fmaf(sy1[e - 16], c, nm));
+            });
+            // elements [n_prev, n_done) got their exponential in the previous gap
+            static_for<n_done - n_prev>([&](auto jc) {
+                constexpr int e = n_prev + decltype(jc)::value;
+                sum += W64_Y(e);
+            });
+#endif
+            // pairs completed (both summed) before the previous gap's additions: [n_prev2/2, n_prev/2)
+            constexpr int n_prev2 = (gi <= 1) ? 0 : ((gi - 2 < 4) ? 2 * (gi - 2) : ((gi - 2 < 28) ? gi + 2 : 32));
+            static_for<n_prev / 2 - n_prev2 / 2>([&](auto jc) {
+                constexpr int q = n_prev2 / 2 + decltype(jc)::value;
+                const f32x2 pr = {W64_Y(2 * q), W64_Y(2 * q + 1)};
+                const half2_t h = __builtin_convertvector(pr, half2_t);
+                pw[q >> 2][q & 3] = __builtin_bit_cast(unsigned, h);
+            });
+        }
+        // ---- vector slice: row max of S_X
+#ifndef W64_ABLATE_MAX
+        if constexpr (gi == 19) {
+            a0 = fmaxf(sx0[0], sx0[1]);
+            a1 = fmaxf(sx1[0], sx1[1]);
+        }
+        if constexpr (gi >= 20 && gi <= 26) {
+            constexpr int k2 = 2 * (gi - 19);
+            a0 = fmaxf(fmaxf(a0, sx0[k2]), sx0[k2 + 1]);
+            a1 = fmaxf(fmaxf(a1, sx1[k2]), sx1[k2 + 1]);
+        }
+        if constexpr (gi == 28) mx_x = half_wave_max(fmaxf(a0, a1)) * c;
+        if constexpr (gi == 30) {
+            // the rescale decision, taken here so that the branch after the phase finds its condition ready
+            need_x = rescale_needed(mx_x, m_x);
+            asm volatile("" : "+s"(need_x));
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    l_y += sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) py[j] = __builtin_bit_cast(half8, pw[j]);
+    // the results are pinned here: the optimiser would otherwise sink the whole vector side into the
+    // block that consumes it
+    asm volatile("" : "+v"(py[0]), "+v"(py[1]), "+v"(py[2]), "+v"(py[3]), "+v"(l_y), "+v"(mx_x));
+#undef W64_Y
+}
+
+// O_X += V^T.P_X^T alone (the stream's last half tile).
+template <int XACC, int VB>
+__device__ __forceinline__ void pv_only(W64Geom& w, const half8 (&px)[4]) {
+    constexpr int VA = W64_V_AHEAD;
+    launder(w);
+    half8 ring[VA];
+#pragma unroll
+    for (int i = 0; i < VA; ++i) ring[i] = read_v_at<VB>(w, i >> 2, i & 3);
+    static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        mfma_acc<XACC + 16 * (i & 3)>(ring[i % VA], px[i >> 2]);
+        if constexpr (i + VA < 16) ring[i % VA] = read_v_at<VB>(w, (i + VA) >> 2, (i + VA) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// S = K.Q^T and its row max for the stream's very first tile (nothing to overlap with yet), and the
+// first K fragments of the phase that follows.
+template <int QBASE>
+__device__ __forceinline__ void first_scores(const W64Geom& w, half8 (&ka0)[W64_K_AHEAD],
+                                             half8 (&ka1)[W64_K_AHEAD], f32x16& sx0, f32x16& sx1, float& mx_x,
+                                             float c) {
+    static_for<8>([&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        const half8 k0 = read_k_at<0>(w, ks, 0), k1 = read_k_at<0>(w, ks, 1);
+        if constexpr (ks == 0) {
+            mfma_s_first<QBASE>(sx0, k0);
+            mfma_s_first<QBASE>(sx1, k1);
+        } else {
+            mfma_s<QBASE + 4 * ks>(sx0, k0);
+            mfma_s<QBASE + 4 * ks>(sx1, k1);
+        }
+    });
+#pragma unroll
+    for (int i = 0; i < W64_K_AHEAD; ++i) {
+        ka0[i] = read_k_at<0>(w, i, 0);
+        ka1[i] = read_k_at<0>(w, i, 1);
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sx0), "+v"(sx1));  // MFMA result -> vector reader
+    float a0 = fmaxf(sx0[0], sx0[1]), a1 = fmaxf(sx1[0], sx1[1]);
+#pragma unroll
+    for (int e = 2; e < 16; e += 2) {
+        a0 = fmaxf(fmaxf(a0, sx0[e]), sx0[e + 1]);
+        a1 = fmaxf(fmaxf(a1, sx1[e]), sx1[e + 1]);
+    }
+    mx_x = half_wave_max(fmaxf(a0, a1)) * c;
+}
+
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
+    constexpr int NWAVES = 4;
+    constexpr int QB = 256;                        // query rows per item
+    constexpr int kImgBytes = 64 * kRowBytes;      // staging image per wave: 64 rows
+    constexpr int kSlots = 3;
+
+    __shared__ __attribute__((aligned(1024))) char k_ring[kSlots * kTileBytes];
+    __shared__ __attribute__((aligned(1024))) char v_ring[kSlots * kTileBytes];
+    __shared__ __attribute__((aligned(1024))) char img_all[NWAVES * kImgBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LaneGeom g = make_lane_geom(lane);
+    char* img = img_all + wave * kImgBytes;  // rows 0-31: sub-block A, rows 32-63: sub-block B
+
+    // ---- DMA geometry: a tile is 16 pieces of 4 rows (1 KiB); this wave moves pieces 4*wave .. 4*wave+3,
+    //      i.e. rows 16*wave + 4j + (lane >> 4).  Consecutive pieces are 1 KiB apart on both sides, so
+    //      one LDS base per tile and the instruction offset address them.  Lane l fills slot l & 15
+    //      of its row with the source chunk the image's swizzle maps there: for K that depends on
+    //      row & 15 = 4j + (lane >> 4), one offset register per piece; for V only on row & 3.
+    const unsigned k_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)k_ring);
+    const unsigned v_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)v_ring);
+    const int d_r4 = lane >> 4, d_slot = lane & 15;
+    const unsigned d_rowoff = (unsigned)((16 * wave + d_r4) * kRowBytes);
+    unsigned d_koff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d_koff[j] = d_rowoff + (unsigned)((d_slot ^ (4 * j + d_r4)) << 4);
+    const unsigned d_voff = d_rowoff + (unsigned)((d_slot ^ (d_r4 << 2)) << 4);
+    const unsigned d_piece = (unsigned)wave * 4096u;
+    W64Geom w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.k_ad[i] = k_lds + (unsigned)g.k_rd[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.v_ad[i] = v_lds + (unsigned)g.v_rd[i];
+
+    const int n_items = p.bh * p.q_blocks;
+    const int n_tiles = p.lk / kKvTile;  // >= 3
+    const int stride = (int)gridDim.x;
+    const float c = p.scale_log2e;
+    constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
+
+    // ---- load cursors (element offsets into K and V): K runs two tiles ahead of the compute
+    //      stream, V one; past the end of the stream they stay on the last tile.
+    struct Cursor {
+        int item, tile;
+        size_t off;
+    };
+#define W64_ADVANCE(cur_)                                                                      \
+    do {                                                                                       \
+        if ((cur_).tile + 1 < n_tiles) {                                                       \
+            ++(cur_).tile;                                                                     \
+            (cur_).off += kTileElems;                                                          \
+        } else if ((cur_).item + stride < n_items) {                                           \
+            (cur_).item += stride;                                                             \
+            (cur_).tile = 0;                                                                   \
+            int h_, q_;                                                                        \
+            decode_item(p, (cur_).item, h_, q_);                                               \
+            (cur_).off = (size_t)h_ * p.lk * kHeadDim;                                         \
+        }                                                                                      \
+    } while (0)
+#define W64_DMA_K(slot_)                                                                       \
+    do {                                                                                       \
+        const half_t* t_ = p.k + kc.off;                                                       \
+        dma_set_base(k_lds + (unsigned)(slot_) * (unsigned)kTileBytes + d_piece);              \
+        dma_piece_at<0>(t_, d_koff[0]);                                                        \
+        dma_piece_at<1024>(t_, d_koff[1]);                                                     \
+        dma_piece_at<2048>(t_, d_koff[2]);                                                     \
+        dma_piece_at<3072>(t_, d_koff[3]);                                                     \
+        W64_ADVANCE(kc);                                                                       \
+    } while (0)
+#define W64_DMA_V(slot_)                                                                       \
+    do {                                                                                       \
+        const half_t* t_ = p.v + vc.off;                                                       \
+        dma_set_base(v_lds + (unsigned)(slot_) * (unsigned)kTileBytes + d_piece);              \
+        dma_piece_at<0>(t_, d_voff);                                                           \
+        dma_piece_at<1024>(t_, d_voff);                                                        \
+        dma_piece_at<2048>(t_, d_voff);                                                        \
+        dma_piece_at<3072>(t_, d_voff);                                                        \
+        W64_ADVANCE(vc);                                                                       \
+    } while (0)
+
+    // ---- compute stream: first item
+    int item = blockIdx.x;
+    int head, qb;
+    decode_item(p, item, head, qb);
+    size_t wrow = (size_t)head * p.lq + (size_t)qb * QB + wave * 64;  // this wave's first query row
+    Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
+    Cursor vc = kc;
+
+    // ---- prologue: K(0), K(1), V(0), the first item's Q rows
+    W64_DMA_K(0);
+    W64_DMA_K(1);
+    W64_DMA_V(0);
+    dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
+    dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
+    wait_all_vmem();
+    __syncthreads();
+
+#ifdef FA_STAMPS  // diagnostic build: shader-clock and 100 MHz counters at entry and exit
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    acc_reserve();
+    q_install<kQregA>(img, lane);
+    q_install<kQregB>(img + 32 * kRowBytes, lane);
+
+    f32x16 sa0, sa1, sb0, sb1;
+    half8 pa[4], pb[4];
+    RowState ra, rb;
+    half8 ka0[W64_K_AHEAD], ka1[W64_K_AHEAD];
+    float mx_a, mx_b;
+    lane_mask_t need_a = 0, need_b = 0;
+
+    // S_A(0) and its state; P_B = 0 makes the first phase's O_B update a no-op on values that
+    // init_state replaces anyway, and S_B needs no value before phase 1 writes it.
+    first_scores<kQregA>(w, ka0, ka1, sa0, sa1, mx_a, c);  // (the next phase reads K(0) again, for B)
+    {
+        f32x16 o[4];
+        init_state(p, wrow + g.r, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
+        acc_store<kAccA>(o);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] = 0.0f;
+        acc_store<kAccB>(o);
+    }
+    rescale_if_needed<kAccA>(rescale_needed(mx_a, ra.m_run), mx_a, ra);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] = half8{};
+    rb.m_run = rb.m_true = -1e30f;
+    rb.l_run = 0.0f;
+
+    size_t out_a = wrow, out_b = 0;  // first row of the item whose O_A / O_B is being accumulated
+    bool b_started = false;          // O_B holds an item (false only before the stream's first phase 1)
+
+#define W64_WRITE_OUT(base_, st_, row_, img_)                                                  \
+    do {                                                                                       \
+        f32x16 o_[4];                                                                          \
+        acc_load<base_>(o_);                                                                   \
+        if (p.flags & kFlagStoreState)                                                         \
+            finish_rows(p, (row_) + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);    \
+        else                                                                                   \
+            store_output_rows(p.o + (row_) * kHeadDim, (img_), lane, o_, (st_).l_run);         \
+    } while (0)
+#define W64_INIT(base_, st_, row_)                                                             \
+    do {                                                                                       \
+        f32x16 o_[4];                                                                          \
+        init_state(p, (row_) + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);         \
+        acc_store<base_>(o_);                                                                  \
+    } while (0)
+
+    // One step.  SC = slot of K(t) and of V(t) (both rings turn together); K(t+1) is in the next slot
+    // and this step's K transfer fills the one after; V(t-1) is in the previous slot and this step's
+    // V transfer fills the next one.  Returns true at the end of the stream.
+    int t = 0;
+    auto step = [&](auto sc) -> bool {
+        constexpr int SC = decltype(sc)::value, SC1 = (SC + 1) % kSlots, SC2 = (SC + 2) % kSlots;
+        const bool first = (t == 0), last = (t + 1 == n_tiles);
+        const int next_item = item + stride;
+        const bool more_items = next_item < n_items;
+
+        // ---- this step's transfers, issued piece by piece inside phase 1: K(t+2), V(t+1)
+        const half_t* k_src = p.k + kc.off;
+        const half_t* v_src = p.v + vc.off;
+        const unsigned k_dst = k_lds + (unsigned)(SC2 * kTileBytes) + d_piece;
+        const unsigned v_dst = v_lds + (unsigned)(SC1 * kTileBytes) + d_piece;
+        W64_ADVANCE(kc);
+        W64_ADVANCE(vc);
+        // pieces 0-3: K, 4-7: V, all inside phase 1 (the V pieces then have phase 2 to land)
+        auto dma_step = [&](auto jc) {
+#ifndef W64_ABLATE_DMA  // (timing experiments only: wrong results)
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j == 0) dma_set_base(k_dst);
+            if constexpr (j == 4) dma_set_base(v_dst);
+            if constexpr (j < 4)
+                dma_piece_at<1024 * j>(k_src, d_koff[j]);
+            else
+                dma_piece_at<1024 * (j - 4)>(v_src, d_voff);
+#endif
+        };
+        auto dma_none = [&](auto) {};
+        // ---- in the last-but-one step: the next item's Q rows
+        int nhead = head, nqb = qb;
+        size_t nwrow = wrow;
+        if (more_items && (t + 2 >= n_tiles)) {
+            decode_item(p, next_item, nhead, nqb);
+            nwrow = (size_t)nhead * p.lq + (size_t)nqb * QB + wave * 64;
+            if (t + 2 == n_tiles) {
+                dma_q_rows_asm(p.q + nwrow * kHeadDim, img, lane);
+                dma_q_rows_asm(p.q + (nwrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
+            }
+        }
+
+        // ---- phase 1: matrix side B (S_B(t), O_B += V(t-1).P_B(t-1)), vector side A
+        if (first && b_started) {
+            // B starts a new item with this phase's scores; its Q rows arrived a step ago
+            q_install<kQregB>(img + 32 * kRowBytes, lane);
+        }
+        fused_phase<kAccB, kQregB, SC * kTileBytes, SC2 * kTileBytes, SC1 * kTileBytes>(
+            w, ka0, ka1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
+        if (first) {
+            // O_B of the previous item is complete: write it out, then start the new item's state
+            if (b_started) W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
+            out_b = wrow;
+            b_started = true;
+            W64_INIT(kAccB, rb, wrow + 32);
+            need_b = rescale_needed(mx_b, rb.m_run);
+        }
+        rescale_if_needed<kAccB>(need_b, mx_b, rb);
+
+        // ---- phase 2: matrix side A (S_A(t+1), O_A += V(t).P_A(t)), vector side B
+        if (last && more_items) q_install<kQregA>(img, lane);  // S_A(t+1) belongs to the next item
+        fused_phase<kAccA, kQregA, SC1 * kTileBytes, SC * kTileBytes, SC1 * kTileBytes>(
+            w, ka0, ka1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
+        if (last) {
+            W64_WRITE_OUT(kAccA, ra, out_a, img);
+            if (!more_items) {
+                // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
+                pv_only<kAccB, SC * kTileBytes>(w, pb);
+                W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
+                wait_all_vmem();  // the last step's (redundant) transfers must not outlive the workgroup's LDS
+#ifdef FA_STAMPS
+                if (p.stamps && tid == 0) {
+                    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+                    o[0] = st_t0;
+                    o[1] = st_r0;
+                    o[2] = __builtin_amdgcn_s_memtime();
+                    o[3] = __builtin_amdgcn_s_memrealtime();
+                }
+#endif
+                return true;
+            }
+            out_a = nwrow;
+            W64_INIT(kAccA, ra, nwrow);
+            need_a = rescale_needed(mx_a, ra.m_run);
+        }
+        rescale_if_needed<kAccA>(need_a, mx_a, ra);
+
+        // ---- end of step
+#ifndef W64_ABLATE_BARRIER  // (timing experiments only: wrong results)
+        wait_all_vmem();
+        __syncthreads();
+#endif
+        if (last) {
+            item = next_item;
+            head = nhead;
+            qb = nqb;
+            wrow = nwrow;
+            t = -1;
+        }
+        ++t;
+        return false;
+    };
+    for (;;) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
+        if (step(std::integral_constant<int, 2>{})) break;
+    }
+}
+
+#undef W64_ADVANCE
+#undef W64_DMA_K
+#undef W64_DMA_V
+#undef W64_WRITE_OUT
+#undef W64_INIT
+
+}  // namespace fa

@@ -15,6 +15,7 @@
 
 #include "fa_fwd_kernel.hpp"
 #include "fa_fwd_ring_kernel.hpp"
+#include "fa_fwd_w64_kernel.hpp"
 
 namespace {
 
@@ -85,7 +86,11 @@ int launch(const fa::FwdParams& base, hipStream_t stream) {
     // + 8 KiB staging image per wave
     bool ring = true;
     if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
-    if (nw == 8 && ring)
+    bool w64 = false;
+    if (const char* e = std::getenv("FA_W64")) w64 = std::atoi(e) != 0;
+    if (nw == 8 && w64 && p.lk >= 3 * fa::kKvTile)
+        hipLaunchKernelGGL(fa::fa_fwd_w64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else if (nw == 8 && ring)
         hipLaunchKernelGGL(fa::fa_fwd_ring_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
     else if (nw == 8)
         hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
