@@ -35,22 +35,16 @@ constexpr int kStageBytes = 2 * kTileBytes;  // K tile, then V tile
 #endif
 constexpr int kRingStages = FA_RING_STAGES;
 
-// One 1 KiB piece (4 rows of 256 B) global -> LDS: lane l fills bytes 16l..16l+15 of the piece with
-// the 16 bytes at base + off (bytes).  m0 carries the piece's LDS address and is restored.  The
-// leading s_nop covers the wait states a scalar base needs when a vector instruction
-// (v_readfirstlane) produced it just before.
-__device__ __forceinline__ void dma_piece(const half_t* base, unsigned off_bytes, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(off_bytes), "s"(base), "s"(lds_addr)
-        : "memory");
+// LDS-DMA of one 1 KiB piece (4 rows of 256 B): the LDS base goes to m0 (dma_set_base), then lane l
+// fills bytes 16l..16l+15 at m0 + OFS with the 16 bytes at base + off + OFS; the compile-time offset
+// is applied by the instruction to BOTH sides.  m0 is left changed: the kernels that use these have
+// no other use for it.
+__device__ __forceinline__ void dma_set_base(unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_addr) : "memory");
+}
+template <int OFS>
+__device__ __forceinline__ void dma_piece_at(const half_t* base, unsigned off_bytes) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(off_bytes), "s"(base), "n"(OFS) : "memory");
 }
 __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -60,12 +54,23 @@ __device__ __forceinline__ void dma_q_rows_asm(const half_t* q_rows, char* img, 
     const int row0 = lane >> 4, slot = lane & 15;
     const unsigned lds_base =
         __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)img);
-    // row = 4i + row0: row & 15 = 4(i&3) + row0, so the swizzled chunk is (slot ^ row0) ^ 4(i&3)
+    // piece i holds rows 4i + row0: row & 15 = 4(i&3) + row0, so the swizzled chunk is
+    // (slot ^ row0) ^ 4(i&3); pieces i and i+4 share it and lie 4 KiB apart on both sides
     const unsigned off0 = (unsigned)(row0 * kRowBytes);
     const int sw = slot ^ row0;
+    unsigned off[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        dma_piece(q_rows + i * 4 * kHeadDim, off0 + (unsigned)((sw ^ (4 * (i & 3))) << 4), lds_base + i * 1024);
+    for (int i = 0; i < 4; ++i) off[i] = off0 + (unsigned)((sw ^ (4 * i)) << 4);
+    dma_set_base(lds_base);
+    dma_piece_at<0>(q_rows, off[0]);
+    dma_piece_at<1024>(q_rows, off[1]);
+    dma_piece_at<2048>(q_rows, off[2]);
+    dma_piece_at<3072>(q_rows, off[3]);
+    dma_set_base(lds_base + 4096u);
+    dma_piece_at<0>(q_rows + 16 * kHeadDim, off[0]);
+    dma_piece_at<1024>(q_rows + 16 * kHeadDim, off[1]);
+    dma_piece_at<2048>(q_rows + 16 * kHeadDim, off[2]);
+    dma_piece_at<3072>(q_rows + 16 * kHeadDim, off[3]);
 }
 
 // First FA_K_AHEAD k-steps of a tile's K operand fragments.
@@ -150,16 +155,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
     const LaneGeom g = make_lane_geom(lane);
     char* img = img_all + wave * (kRowsPerWave * kRowBytes);
 
-    // ---- DMA geometry.  A tile is 16 pieces of 4 rows; this wave moves pieces `wave` and `wave + 8`
-    //      of the K tile and of the V tile.  Lane l of a piece fills slot l & 15 of row 4*piece + (l >> 4)
-    //      with the source chunk that the image's swizzle maps there (row & 15 and row & 3 are the
-    //      same for both pieces, which are 32 rows apart).
+    // ---- DMA geometry.  A tile is 16 pieces of 4 rows (1 KiB); this wave moves pieces 2*wave and
+    //      2*wave + 1 of the K tile and of the V tile, i.e. rows 8*wave + 4j + (lane >> 4).  The two
+    //      pieces are 1 KiB apart on both sides, so one LDS base and the instruction offset address
+    //      them.  Lane l fills slot l & 15 of its row with the source chunk the image's swizzle maps
+    //      there: for K that depends on row & 15 (one offset register per piece), for V on row & 3.
     const unsigned ring_lds =
         __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
-    const int d_row = 4 * wave + (lane >> 4), d_slot = lane & 15;
-    const unsigned d_koff = (unsigned)(d_row * kRowBytes + ((d_slot ^ (d_row & 15)) << 4));
-    const unsigned d_voff = (unsigned)(d_row * kRowBytes + ((d_slot ^ ((d_row & 3) << 2)) << 4));
-    const unsigned d_lds = ring_lds + (unsigned)wave * 1024u;
+    const int d_r4 = lane >> 4, d_slot = lane & 15;
+    const unsigned d_rowoff = (unsigned)((8 * wave + d_r4) * kRowBytes);
+    const unsigned d_koff0 = d_rowoff + (unsigned)((d_slot ^ ((8 * wave + d_r4) & 15)) << 4);
+    const unsigned d_koff1 = d_rowoff + (unsigned)((d_slot ^ ((8 * wave + 4 + d_r4) & 15)) << 4);
+    const unsigned d_voff = d_rowoff + (unsigned)((d_slot ^ (d_r4 << 2)) << 4);
+    const unsigned d_lds = ring_lds + (unsigned)wave * 2048u;
 
     const int n_items = p.bh * p.q_blocks;
     const int n_tiles = p.lk / kKvTile;
@@ -186,10 +194,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
         const half_t* kt_ = p.k + c_off;                                                       \
         const half_t* vt_ = p.v + c_off;                                                       \
         const unsigned l_ = d_lds + (unsigned)(stage_) * (unsigned)kStageBytes;                \
-        dma_piece(kt_, d_koff, l_);                                                            \
-        dma_piece(kt_ + 32 * kHeadDim, d_koff, l_ + 8192u);                                    \
-        dma_piece(vt_, d_voff, l_ + (unsigned)kTileBytes);                                     \
-        dma_piece(vt_ + 32 * kHeadDim, d_voff, l_ + (unsigned)kTileBytes + 8192u);             \
+        dma_set_base(l_);                                                                      \
+        dma_piece_at<0>(kt_, d_koff0);                                                         \
+        dma_piece_at<1024>(kt_, d_koff1);                                                      \
+        dma_set_base(l_ + (unsigned)kTileBytes);                                               \
+        dma_piece_at<0>(vt_, d_voff);                                                          \
+        dma_piece_at<1024>(vt_, d_voff);                                                       \
         if (c_tile + 1 < n_tiles) {                                                            \
             ++c_tile;                                                                          \
             c_off += kTileElems;                                                               \
@@ -202,6 +212,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
         }                                                                                      \
     } while (0)
 
+#ifdef FA_STAMPS  // diagnostic build: 100 MHz time stamps of wave 0 at entry, after the prologue, after every step
+    int n_stamp = 0;
+#define RING_STAMP()                                                                           \
+    do {                                                                                       \
+        if (p.stamps && tid == 0 && n_stamp < 60)                                              \
+            p.stamps[(size_t)blockIdx.x * 64 + n_stamp++] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#else
+#define RING_STAMP() do {} while (0)
+#endif
+    RING_STAMP();
     // ---- prologue: tiles 0 and 1 of the stream and the first item's Q rows
     half8 qf[8];
     half8 ka0[FA_K_AHEAD], ka1[FA_K_AHEAD];
@@ -210,6 +231,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
     dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
     wait_all_vmem();
     __syncthreads();
+    RING_STAMP();
     fetch_q_frags(qf, img, lane);
     k_prefetch(ring, g, ka0, ka1);
 
@@ -264,6 +286,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
             if (!more_items) {
                 if (out_valid) RING_WRITE_OUT();
                 wait_all_vmem();  // the last step's (redundant) transfer must not outlive the workgroup's LDS
+                RING_STAMP();
                 break;
             }
         }
@@ -282,10 +305,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_ring_kernel(const FwdPa
         st = (st == kRingStages - 1) ? 0 : st + 1;
         k_prefetch(ring + st * kStageBytes, g, ka0, ka1);  // tile g+1: complete since the last barrier
         __syncthreads();
+        RING_STAMP();
         ++t;
     }
 }
 
+#undef RING_STAMP
 #undef RING_DMA_TILE
 #undef RING_WRITE_OUT
 

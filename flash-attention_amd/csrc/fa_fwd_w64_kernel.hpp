@@ -55,17 +55,6 @@ struct RowState {
     float m_run, m_true, l_run;
 };
 
-// LDS-DMA of one 1 KiB piece with the LDS base already in m0: lane l fills bytes 16l..16l+15 at
-// m0 + OFS with the 16 bytes at base + off + OFS (the instruction offset applies to both sides).
-// m0 is left changed: nothing else in this kernel uses it.
-__device__ __forceinline__ void dma_set_base(unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_addr) : "memory");
-}
-template <int OFS>
-__device__ __forceinline__ void dma_piece_at(const half_t* base, unsigned off_bytes) {
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(off_bytes), "s"(base), "n"(OFS) : "memory");
-}
-
 // compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ...
 template <typename F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 fa = ge.load_package()
-L_ = ct.CDLL(os.path.join(ROOT, "build_ab", "stamps.so"))
+L_ = ct.CDLL(os.path.join(ROOT, "build_ab", os.environ.get("FA_STAMPS_LIB", "stamps.so")))
 sig = [fa.HalfPtr] * 4 + [ct.c_int] * 5 + [ct.c_void_p, ct.POINTER(ct.c_float)]
 L_.fa_forward.argtypes = sig; L_.fa_forward.restype = ct.c_int
 L_.fa_debug_set_stamps.argtypes = [ct.c_void_p]
@@ -32,9 +32,6 @@ for L in [int(x) for x in sys.argv[1:]] or [512, 1024, 2048]:
     raw = stamps.cpu().numpy().reshape(256, 64).astype(np.float64)
     s = raw / 100.0  # us
     nst = int((s[0, :60] > 0).sum())
-    dt_real = raw[:, nst - 1] - raw[:, 0]
-    dt_clk = raw[:, 63] - raw[:, 62]
-    print(f"    shader clock during the kernel: median {np.median(dt_clk / dt_real * 100):.0f} MHz")
     t0 = s[:, 0].min()
     rel = s[:, :nst] - t0
     print(f"--- L={L}: {nst} stamps per workgroup; kernel span {rel.max():.1f} us; start spread {rel[:,0].max():.2f} us")
