@@ -29,21 +29,26 @@ def counters(path):
     return {k: sum(v) / len(v) for k, v in acc.items()}, meta
 
 
+def newest(pattern):
+    """gpurun merges every run's files into the same directory: take the latest run's."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def main():
     L = int(sys.argv[1])
     tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
     src = os.path.join(ROOT, "gpurun_out", f"prof_L{L}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(dst, f"{tag}_L{L}_kernel_stats.csv"))
     kern = None
     for r in csv.DictReader(open(stats)):
         if "fa_fwd" in r["Name"]:
             kern = r
-    sq, meta = counters(glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv"))[0])
-    fetch, _ = counters(glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))[0])
-    write, _ = counters(glob.glob(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))[0])
+    sq, meta = counters(newest(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv")))
+    fetch, _ = counters(newest(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")))
+    write, _ = counters(newest(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv")))
     B, H, D = 16384 // L, 16, 128
     flops = 4.0 * B * H * L * L * D
     avg_ns = float(kern["AverageNs"])
