@@ -21,13 +21,14 @@
 // 32 cycles).  The rescale decision is the only branch and sits between the blocks, where no MFMA
 // is writing the accumulator.
 //
-// K therefore runs one tile ahead of V.  LDS: a K ring and a V ring of three 16 KiB slots each, both
-// filled by DMA (global_load_lds, hidden from the compiler as in fa_fwd_ring_kernel).  In step t the
-// waves read K(t), K(t+1), V(t-1), V(t); K(t+2) and V(t+1) are in flight into the slots of K(t-1)
-// and V(t-2), whose last readers finished before the barrier that ended step t-1.  One barrier per
-// step, at its end, after each wave has waited for its own DMA.  The first K fragments of the next
-// phase are always read at the end of the current one (they were published at least one barrier
-// earlier), so no phase opens with an exposed LDS round trip.
+// K therefore runs one tile ahead of V, and the tile one sub-block multiplies in a phase 2 is the one
+// the other multiplies in the following phase 1.  The K fragments of a tile (64 registers) and its
+// V^T fragments (64 accumulator registers) therefore stay in registers for two phases and every
+// fragment is read from LDS once; phase 1 re-fills each slot right after its last use, phase 2
+// reads nothing.  LDS: a K ring and a V ring of three 16 KiB slots each, both filled by DMA
+// (global_load_lds, hidden from the compiler as in fa_fwd_ring_kernel) two steps ahead of their
+// use.  One barrier per step, at its end, after each wave has waited for everything but the step's
+// own transfers.
 //
 // Items (head, 256-row query block) form one stream of tiles per workgroup, as in the other
 // kernels.  The next item's Q rows are DMAed into the wave's 16 KiB staging image during the item's
@@ -84,6 +85,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kAccA = 0, kAccB = 64;     // O^T of sub-blocks A and B
 constexpr int kQregA = 128, kQregB = 160;  // their Q fragments: k-step ks in a[base + 4ks : base + 4ks + 3]
+constexpr int kVbuf = 192;                 // V^T fragments of one tile: fragment i in a[192 + 4i : 192 + 4i + 3]
 
 __device__ __forceinline__ void acc_reserve() {
     asm volatile(""
@@ -104,7 +106,13 @@ __device__ __forceinline__ void acc_reserve() {
                    "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158",
                    "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170",
                    "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182",
-                   "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+                   "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194",
+                   "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206",
+                   "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218",
+                   "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230",
+                   "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242",
+                   "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254",
+                   "a255");
 }
 // S (architectural registers): d = a.q  /  d += a.q, with q = a[QLO:QLO+3]
 template <int QLO>
@@ -122,6 +130,24 @@ __device__ __forceinline__ void mfma_acc(const half8& a, const half8& b) {
                  :
                  : "v"(a), "v"(b), "n"(LO), "n"(LO + 15));
 }
+// O: a[LO:LO+15] += v.b with the V^T fragment v taken from a[VLO:VLO+3]
+template <int LO, int VLO>
+__device__ __forceinline__ void mfma_acc_av(const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%1:%2], a[%3:%4], %0, a[%1:%2]"
+                 :
+                 : "v"(b), "n"(LO), "n"(LO + 15), "n"(VLO), "n"(VLO + 3));
+}
+// One V^T fragment (two transposed 8-byte reads) straight into a[VLO:VLO+3].  The compiler does
+// not see these reads: their completion is awaited by hand (lds_wait_all) before the MFMAs that
+// use the registers.  Its own counted waits for the reads it does see can only become longer.
+template <int VLO, int OFS>
+__device__ __forceinline__ void vbuf_read(unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 a[%1:%2], %0 offset:%5\n\tds_read_b64_tr_b16 a[%3:%4], %0 offset:%6"
+                 :
+                 : "v"(addr), "n"(VLO), "n"(VLO + 1), "n"(VLO + 2), "n"(VLO + 3), "n"(OFS), "n"(OFS + 8 * kRowBytes)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Wait states between the last MFMA on an accumulator and a v_accvgpr_read of it.
 __device__ __forceinline__ void acc_fence() { asm volatile("s_nop 15\n\ts_nop 3"); }
 template <int R>
@@ -229,35 +255,35 @@ __device__ __forceinline__ half8 read_v_at(const W64Geom& w, int kk, int db) {
 // One phase (see the file comment), written out gap by gap: 32 MFMAs, and after each of them the
 // LDS reads and the slice of vector work that share its 32 cycles; sched_barrier(0) after every gap
 // keeps the compiler from re-ordering across gaps.  X is the sub-block on the matrix side
-// (accumulator base XACC), Y the one on the vector side.
-//   KB       K slot (byte offset in the K ring) for S_X = K.Q_X^T;  ka0/ka1: its first W64_K_AHEAD
-//            k-steps, already read
-//   VB       V slot for O_X += V^T.P_X^T
-//   KB_NEXT  K slot of the NEXT phase: its first k-steps are read into ka0/ka1 in the last gaps
+// (accumulator base XACC, Q fragments at QBASE), Y the one on the vector side.
+//
+// Operands.  The K fragments of one tile (kb0/kb1: key blocks 0 and 1, k-steps 0-7, 64 registers) and
+// the V^T fragments of one tile (a[kVbuf..], 64 registers) stay in registers for TWO consecutive
+// phases, so that both sub-blocks use them and every fragment is read from LDS once: sub-block A is
+// half a tile ahead, so the tile A multiplies in a phase 2 is the one B multiplies in the following
+// phase 1.  Phase 1 (REFILL) therefore re-fills each slot right after its MFMA has taken it: k-step ks
+// of the next K tile after gaps 2ks / 2ks+1, fragment i of the next V tile after gap 16+i.  Phase 2 reads
+// nothing from LDS.  Data returning from LDS competes with vector instructions for the register
+// file's write port (measured: 48 reads + the vector slice cost 13 cycles per MFMA more than either
+// alone), which is why halving the reads matters.
+//   KB_NEXT  K slot (byte offset in the K ring) the refill reads     VB_NEXT  V slot the refill reads
 //   sx0/sx1  out: S_X                          mx_x     out: scaled row max of S_X
 //   m_x      X's running reference max         need_x   out: rescale_needed(mx_x, m_x)
 //   sy0/sy1  in: S_Y (overwritten by p)        py       out: P_Y fragments;   l_y += row sum
-// Gaps 0-15 are S_X (k-step g/2, key block g&1), gaps 16-31 O_X (V fragment g-16).  The row max of
-// S_X starts in gap 19, three MFMAs after the last one that wrote S_X.
 //   dma(j)   issues piece j (0..7) of the step's tile transfers (j is an integral_constant); called in
 //            gaps 2, 6, 10, ... 30
-template <int XACC, int QBASE, int KB, int VB, int KB_NEXT, typename DMA>
-__device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&ka0)[W64_K_AHEAD],
-                                            half8 (&ka1)[W64_K_AHEAD], f32x16& sx0, f32x16& sx1,
-                                            const half8 (&px)[4], float& mx_x, float m_x, lane_mask_t& need_x, f32x16& sy0,
-                                            f32x16& sy1, float m_y, float& l_y, half8 (&py)[4], float c, DMA&& dma) {
-    constexpr int KA = W64_K_AHEAD, VA = W64_V_AHEAD;
-    static_assert(KA >= 1 && KA <= 4 && (VA == 2 || VA == 4 || VA == 6 || VA == 8), "ring depths");
+// Gaps 0-15 are S_X (k-step g/2, key block g&1), gaps 16-31 O_X (V fragment g-16).  The row max of
+// S_X starts in gap 19, three MFMAs after the last one that wrote S_X.
+template <bool REFILL, int XACC, int QBASE, int KB_NEXT, int VB_NEXT, typename DMA>
+__device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (&kb1)[8], f32x16& sx0, f32x16& sx1,
+                                            const half8 (&px)[4], float& mx_x, float m_x, lane_mask_t& need_x,
+                                            f32x16& sy0, f32x16& sy1, float m_y, float& l_y, half8 (&py)[4], float c,
+                                            DMA&& dma) {
     launder(w);
-    half8 ring[VA];
-#ifdef W64_ABLATE_VREAD
-#pragma unroll
-    for (int i = 0; i < VA; ++i) ring[i] = ka0[0];
-#endif
     const float nm = -m_y;
     float sum = 0.0f;
     float a0 = 0.0f, a1 = 0.0f;
-    u32x4 pw[4];
+    u32x4 pw[4] = {};
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #define W64_Y(e_) (((e_) < 16) ? sy0[(e_) & 15] : sy1[(e_) & 15])
     static_for<32>([&](auto ic) {
@@ -266,49 +292,39 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&ka0)[W64_K_AHEAD
         if constexpr (gi < 16) {
             constexpr int ks = gi >> 1;
             if constexpr (gi == 0)
-                mfma_s_first<QBASE>(sx0, ka0[0]);
+                mfma_s_first<QBASE>(sx0, kb0[0]);
             else if constexpr (gi == 1)
-                mfma_s_first<QBASE>(sx1, ka1[0]);
+                mfma_s_first<QBASE>(sx1, kb1[0]);
             else if constexpr (gi & 1)
-                mfma_s<QBASE + 4 * ks>(sx1, ka1[ks % KA]);
+                mfma_s<QBASE + 4 * ks>(sx1, kb1[ks]);
             else
-                mfma_s<QBASE + 4 * ks>(sx0, ka0[ks % KA]);
+                mfma_s<QBASE + 4 * ks>(sx0, kb0[ks]);
         } else {
             constexpr int i = gi - 16;
-            mfma_acc<XACC + 16 * (i & 3)>(ring[i % VA], px[i >> 2]);
+            // all V fragments were requested at least a phase ago; the one wait sits where it cannot stall
+            if constexpr (i == 0 && !REFILL) lds_wait_all();
+            mfma_acc_av<XACC + 16 * (i & 3), kVbuf + 4 * i>(px[i >> 2]);
         }
         // ---- this gap's share of the tile transfer
         if constexpr ((gi & 3) == 2) dma(std::integral_constant<int, (gi >> 2)>{});
-        // ---- LDS reads
+        // ---- LDS reads: re-fill the slot the MFMA above has just taken
+        if constexpr (REFILL) {
 #ifndef W64_ABLATE_KREAD
-        if constexpr (gi < 16 && (gi & 1)) {  // both MFMAs of k-step gi/2 have taken their fragments
-            constexpr int ks = gi >> 1;
-            if constexpr (ks + KA < 8) {  // key block 1 first: one wait, before the block-0 MFMA, covers both
-                ka1[ks % KA] = read_k_at<KB>(w, ks + KA, 1);
-                ka0[ks % KA] = read_k_at<KB>(w, ks + KA, 0);
+            if constexpr (gi < 16) {
+                constexpr int ks = gi >> 1;
+                if constexpr (gi & 1)
+                    kb1[ks] = read_k_at<KB_NEXT>(w, ks, 1);
+                else
+                    kb0[ks] = read_k_at<KB_NEXT>(w, ks, 0);
             }
-        }
 #endif
 #ifndef W64_ABLATE_VREAD
-        // V fragments in pairs, the later-used one first, every other gap
-        if constexpr (gi >= 16 - VA && gi < 16 && ((gi - (16 - VA)) & 1) == 0) {
-            constexpr int i = gi - (16 - VA);
-            ring[i + 1] = read_v_at<VB>(w, (i + 1) >> 2, (i + 1) & 3);
-            ring[i] = read_v_at<VB>(w, i >> 2, i & 3);
-        }
-        if constexpr (gi >= 16 && ((gi - 16) & 1) == 1 && gi - 16 - 1 + VA < 16) {
-            constexpr int i = gi - 16 - 1 + VA;  // MFMAs gi-1 and gi have taken fragments i-VA, i-VA+1
-            ring[(i + 1) % VA] = read_v_at<VB>(w, (i + 1) >> 2, (i + 1) & 3);
-            ring[i % VA] = read_v_at<VB>(w, i >> 2, i & 3);
-        }
+            if constexpr (gi >= 16) {
+                constexpr int i = gi - 16;
+                vbuf_read<kVbuf + 4 * i, VB_NEXT + (i >> 2) * 16 * kRowBytes>(w.v_ad[i & 3]);
+            }
 #endif
-#ifndef W64_ABLATE_KREAD
-        if constexpr (gi >= 32 - KA) {
-            constexpr int j = gi - (32 - KA);
-            ka1[j] = read_k_at<KB_NEXT>(w, j, 1);
-            ka0[j] = read_k_at<KB_NEXT>(w, j, 0);
         }
-#endif
         // ---- vector slice: Y's 32 scores, two per gap in gaps 0-3 and one per gap in gaps 4-27 (so that
         //      the whole slice is finished inside the phase); each element is summed one gap after
         //      its exponential, each pair rounded to fp16 one gap after that
@@ -368,44 +384,36 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&ka0)[W64_K_AHEAD
 #undef W64_Y
 }
 
-// O_X += V^T.P_X^T alone (the stream's last half tile).
-template <int XACC, int VB>
-__device__ __forceinline__ void pv_only(W64Geom& w, const half8 (&px)[4]) {
-    constexpr int VA = W64_V_AHEAD;
-    launder(w);
-    half8 ring[VA];
-#pragma unroll
-    for (int i = 0; i < VA; ++i) ring[i] = read_v_at<VB>(w, i >> 2, i & 3);
+// O_X += V^T.P_X^T alone (the stream's last half tile), from the fragments already in registers.
+template <int XACC>
+__device__ __forceinline__ void pv_only(const half8 (&px)[4]) {
+    lds_wait_all();
     static_for<16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        mfma_acc<XACC + 16 * (i & 3)>(ring[i % VA], px[i >> 2]);
-        if constexpr (i + VA < 16) ring[i % VA] = read_v_at<VB>(w, (i + VA) >> 2, (i + VA) & 3);
-        __builtin_amdgcn_sched_barrier(0);
+        mfma_acc_av<XACC + 16 * (i & 3), kVbuf + 4 * i>(px[i >> 2]);
     });
 }
 
-// S = K.Q^T and its row max for the stream's very first tile (nothing to overlap with yet), and the
-// first K fragments of the phase that follows.
+// The stream's very first tile: its K fragments into the buffer (they stay for the first phase 1),
+// S = K.Q^T and its row max (nothing to overlap with yet).
 template <int QBASE>
-__device__ __forceinline__ void first_scores(const W64Geom& w, half8 (&ka0)[W64_K_AHEAD],
-                                             half8 (&ka1)[W64_K_AHEAD], f32x16& sx0, f32x16& sx1, float& mx_x,
-                                             float c) {
+__device__ __forceinline__ void first_scores(W64Geom& w, half8 (&kb0)[8], half8 (&kb1)[8], f32x16& sx0, f32x16& sx1,
+                                             float& mx_x, float c) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        kb0[ks] = read_k_at<0>(w, ks, 0);
+        kb1[ks] = read_k_at<0>(w, ks, 1);
+    }
     static_for<8>([&](auto ic) {
         constexpr int ks = decltype(ic)::value;
-        const half8 k0 = read_k_at<0>(w, ks, 0), k1 = read_k_at<0>(w, ks, 1);
         if constexpr (ks == 0) {
-            mfma_s_first<QBASE>(sx0, k0);
-            mfma_s_first<QBASE>(sx1, k1);
+            mfma_s_first<QBASE>(sx0, kb0[0]);
+            mfma_s_first<QBASE>(sx1, kb1[0]);
         } else {
-            mfma_s<QBASE + 4 * ks>(sx0, k0);
-            mfma_s<QBASE + 4 * ks>(sx1, k1);
+            mfma_s<QBASE + 4 * ks>(sx0, kb0[ks]);
+            mfma_s<QBASE + 4 * ks>(sx1, kb1[ks]);
         }
     });
-#pragma unroll
-    for (int i = 0; i < W64_K_AHEAD; ++i) {
-        ka0[i] = read_k_at<0>(w, i, 0);
-        ka1[i] = read_k_at<0>(w, i, 1);
-    }
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sx0), "+v"(sx1));  // MFMA result -> vector reader
     float a0 = fmaxf(sx0[0], sx0[1]), a1 = fmaxf(sx1[0], sx1[1]);
 #pragma unroll
@@ -458,8 +466,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     const float c = p.scale_log2e;
     constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
 
-    // ---- load cursors (element offsets into K and V): K runs two tiles ahead of the compute
-    //      stream, V one; past the end of the stream they stay on the last tile.
+    // ---- load cursors (element offsets into K and V): the tile the next transfer fetches.  K runs
+    //      three tiles ahead of the compute stream, V two; past the end of the stream they stay on the
+    //      last tile (redundant transfers into slots nobody reads any more).
     struct Cursor {
         int item, tile;
         size_t off;
@@ -506,10 +515,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
     Cursor vc = kc;
 
-    // ---- prologue: K(0), K(1), V(0), the first item's Q rows
+    // ---- prologue: K(0..2), V(0..1), the first item's Q rows
     W64_DMA_K(0);
     W64_DMA_K(1);
+    W64_DMA_K(2);
     W64_DMA_V(0);
+    W64_DMA_V(1);
     dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
     dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
     wait_all_vmem();
@@ -525,13 +536,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     f32x16 sa0, sa1, sb0, sb1;
     half8 pa[4], pb[4];
     RowState ra, rb;
-    half8 ka0[W64_K_AHEAD], ka1[W64_K_AHEAD];
+    half8 kb0[8], kb1[8];  // K fragments of the tile both sub-blocks multiply next (key blocks 0 / 1)
     float mx_a, mx_b;
     lane_mask_t need_a = 0, need_b = 0;
 
     // S_A(0) and its state; P_B = 0 makes the first phase's O_B update a no-op on values that
     // init_state replaces anyway, and S_B needs no value before phase 1 writes it.
-    first_scores<kQregA>(w, ka0, ka1, sa0, sa1, mx_a, c);  // (the next phase reads K(0) again, for B)
+    first_scores<kQregA>(w, kb0, kb1, sa0, sa1, mx_a, c);
     {
         f32x16 o[4];
         init_state(p, wrow + g.r, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
@@ -567,9 +578,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         acc_store<base_>(o_);                                                                  \
     } while (0)
 
-    // One step.  SC = slot of K(t) and of V(t) (both rings turn together); K(t+1) is in the next slot
-    // and this step's K transfer fills the one after; V(t-1) is in the previous slot and this step's
-    // V transfer fills the next one.  Returns true at the end of the stream.
+    // One step.  Tile j of either ring lives in slot j % 3; SC = t % 3.  Phase 1 re-fills the fragment
+    // buffers from K(t+1) (slot SC1) and V(t) (slot SC) while this step's transfers, K(t+3) and V(t+2),
+    // go to slots SC and SC2, whose tiles K(t) and V(t-1) were last read in step t-1.  The transfers
+    // have two steps to land: the wait at the end of a step leaves the step's own eight pieces in
+    // flight.  Returns true at the end of the stream.
     int t = 0;
     auto step = [&](auto sc) -> bool {
         constexpr int SC = decltype(sc)::value, SC1 = (SC + 1) % kSlots, SC2 = (SC + 2) % kSlots;
@@ -577,14 +590,14 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         const int next_item = item + stride;
         const bool more_items = next_item < n_items;
 
-        // ---- this step's transfers, issued piece by piece inside phase 1: K(t+2), V(t+1)
+        // ---- this step's transfers, issued piece by piece inside phase 1: K(t+3), V(t+2)
         const half_t* k_src = p.k + kc.off;
         const half_t* v_src = p.v + vc.off;
-        const unsigned k_dst = k_lds + (unsigned)(SC2 * kTileBytes) + d_piece;
-        const unsigned v_dst = v_lds + (unsigned)(SC1 * kTileBytes) + d_piece;
+        const unsigned k_dst = k_lds + (unsigned)(SC * kTileBytes) + d_piece;
+        const unsigned v_dst = v_lds + (unsigned)(SC2 * kTileBytes) + d_piece;
         W64_ADVANCE(kc);
         W64_ADVANCE(vc);
-        // pieces 0-3: K, 4-7: V, all inside phase 1 (the V pieces then have phase 2 to land)
+        // pieces 0-3: K, 4-7: V
         auto dma_step = [&](auto jc) {
 #ifndef W64_ABLATE_DMA  // (timing experiments only: wrong results)
             constexpr int j = decltype(jc)::value;
@@ -614,8 +627,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             // B starts a new item with this phase's scores; its Q rows arrived a step ago
             q_install<kQregB>(img + 32 * kRowBytes, lane);
         }
-        fused_phase<kAccB, kQregB, SC * kTileBytes, SC2 * kTileBytes, SC1 * kTileBytes>(
-            w, ka0, ka1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
+        fused_phase<true, kAccB, kQregB, SC1 * kTileBytes, SC * kTileBytes>(
+            w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
         if (first) {
             // O_B of the previous item is complete: write it out, then start the new item's state
             if (b_started) W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
@@ -628,13 +641,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 
         // ---- phase 2: matrix side A (S_A(t+1), O_A += V(t).P_A(t)), vector side B
         if (last && more_items) q_install<kQregA>(img, lane);  // S_A(t+1) belongs to the next item
-        fused_phase<kAccA, kQregA, SC1 * kTileBytes, SC * kTileBytes, SC1 * kTileBytes>(
-            w, ka0, ka1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
+        fused_phase<false, kAccA, kQregA, 0, 0>(
+            w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
         if (last) {
             W64_WRITE_OUT(kAccA, ra, out_a, img);
             if (!more_items) {
                 // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
-                pv_only<kAccB, SC * kTileBytes>(w, pb);
+                pv_only<kAccB>(pb);
                 W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
                 wait_all_vmem();  // the last step's (redundant) transfers must not outlive the workgroup's LDS
 #ifdef FA_STAMPS
@@ -656,7 +669,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 
         // ---- end of step
 #ifndef W64_ABLATE_BARRIER  // (timing experiments only: wrong results)
-        wait_all_vmem();
+        // everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
 #endif
         if (last) {

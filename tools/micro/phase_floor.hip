@@ -1,0 +1,95 @@
+// Microbenchmark: the fused phase of fa_fwd_w64_kernel in isolation (LDS content arbitrary but
+// finite, no tile transfers unless asked), cycles per MFMA, one wave per SIMD, every CU busy.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../../flash-attention_amd/csrc/fa_fwd_w64_kernel.hpp"
+using namespace fa;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k(unsigned long long* out, const half_t* src, int iters) {
+    __shared__ __attribute__((aligned(1024))) char k_ring[3 * kTileBytes];
+    __shared__ __attribute__((aligned(1024))) char v_ring[3 * kTileBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 3 * kTileBytes / 4; i += 256) {
+        ((float*)k_ring)[i] = 0.0f;
+        ((float*)v_ring)[i] = 0.0f;
+    }
+    __syncthreads();
+    const LaneGeom g = make_lane_geom(lane);
+    const unsigned k_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)k_ring);
+    const unsigned v_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)v_ring);
+    W64Geom w;
+    for (int i = 0; i < 8; ++i) w.k_ad[i] = k_lds + (unsigned)g.k_rd[i];
+    for (int i = 0; i < 4; ++i) w.v_ad[i] = v_lds + (unsigned)g.v_rd[i];
+    acc_reserve();
+    {
+        f32x16 z[4] = {};
+        acc_store<kAccA>(z);
+        acc_store<kAccB>(z);
+        static_for<64>([&](auto ic) { acc_put_u32<128 + decltype(ic)::value>(0u); });
+    }
+    f32x16 sa0 = {}, sa1 = {}, sb0 = {}, sb1 = {};
+    half8 pa[4] = {}, pb[4] = {};
+    half8 ka0[W64_K_AHEAD] = {}, ka1[W64_K_AHEAD] = {};
+    float mx_a = 0, mx_b = 0, la = 0, lb = 0, ma = 0, mb = 0;
+    lane_mask_t need_a = 0, need_b = 0;
+    const unsigned d_off = (unsigned)(lane * 16);
+    const unsigned d_piece = (unsigned)wave * 4096u;
+    auto dma_none = [&](auto) {};
+    auto dma_step = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j == 0) dma_set_base(k_lds + 2 * kTileBytes + d_piece);
+        if constexpr (j == 4) dma_set_base(v_lds + 2 * kTileBytes + d_piece);
+        dma_piece_at<1024 * (j & 3)>(src + (size_t)blockIdx.x * 32768 + wave * 2048, d_off);
+    };
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0 || MODE == 1 || MODE == 2) {
+            fused_phase<kAccB, kQregB, 0, kTileBytes, kTileBytes>(w, ka0, ka1, sb0, sb1, pb, mx_b, mb, need_b, sa0, sa1, ma, la, pa, 0.001f, dma_none);
+            if constexpr (MODE >= 1) { RowState r{mb, mb, lb}; rescale_if_needed<kAccB>(need_b, mx_b, r); mb = r.m_run; lb = r.l_run; }
+            fused_phase<kAccA, kQregA, kTileBytes, 0, kTileBytes>(w, ka0, ka1, sa0, sa1, pa, mx_a, ma, need_a, sb0, sb1, mb, lb, pb, 0.001f, dma_none);
+            if constexpr (MODE >= 1) { RowState r{ma, ma, la}; rescale_if_needed<kAccA>(need_a, mx_a, r); ma = r.m_run; la = r.l_run; }
+            if constexpr (MODE >= 2) __syncthreads();
+        } else {
+            fused_phase<kAccB, kQregB, 0, kTileBytes, kTileBytes>(w, ka0, ka1, sb0, sb1, pb, mx_b, mb, need_b, sa0, sa1, ma, la, pa, 0.001f, dma_step);
+            { RowState r{mb, mb, lb}; rescale_if_needed<kAccB>(need_b, mx_b, r); mb = r.m_run; lb = r.l_run; }
+            fused_phase<kAccA, kQregA, kTileBytes, 0, kTileBytes>(w, ka0, ka1, sa0, sa1, pa, mx_a, ma, need_a, sb0, sb1, mb, lb, pb, 0.001f, dma_none);
+            { RowState r{ma, ma, la}; rescale_if_needed<kAccA>(need_a, mx_a, r); ma = r.m_run; la = r.l_run; }
+            wait_all_vmem();
+            __syncthreads();
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_nop 15\ns_nop 15");
+    float s = sa0[0] + sb1[1] + la + lb + (float)pa[0][0] + (float)pb[1][1];
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (s == 12345.678f) out[0] = 0;
+}
+
+template <int MODE>
+void run(const char* name) {
+    unsigned long long* d;
+    half_t* src;
+    hipMalloc(&d, 256 * 8);
+    hipMalloc(&src, 256 * 65536 + 65536);
+    hipMemset(src, 0, 256 * 65536 + 65536);
+    const int iters = 1000;
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, d, src, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256);
+    hipMemcpy(h.data(), d, 256 * 8, hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (auto v : h) sum += (double)v;
+    printf("%-70s %.2f cycles per MFMA\n", name, sum / 256 / iters / 64);
+    hipFree(d);
+    hipFree(src);
+}
+int main() {
+    run<0>("two fused phases back to back");
+    run<1>("+ rescale decision branch between phases");
+    run<2>("+ workgroup barrier per step");
+    run<3>("+ 8 DMA pieces per step, vmcnt(0) before the barrier");
+    return 0;
+}
