@@ -216,7 +216,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_TFLOPS,
             "traffic": measured_traffic(L),
-            "kernel": "fa::fa_fwd_ring_kernel<8>",
+            "kernel": fa.lib().fa_kernel_name(L, L).decode(),
             "kernel_ms": ms_launch,
             "algorithmic_bytes": 4 * n_local * 2,
             "algorithmic_GBps": 4 * n_local * 2 / (ms_launch * 1e-3) / 1e9,

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "fa_device_info",
     "fa_last_error",
     "fa_version",
+    "fa_kernel_name",
 )
 
 _lib = None
@@ -77,6 +78,8 @@ def lib() -> ct.CDLL:
         L.fa_last_error.restype = ct.c_char_p
         L.fa_version.argtypes = []
         L.fa_version.restype = ct.c_char_p
+        L.fa_kernel_name.argtypes = [ct.c_int, ct.c_int]
+        L.fa_kernel_name.restype = ct.c_char_p
         _lib = L
     return _lib
 

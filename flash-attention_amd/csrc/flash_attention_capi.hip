@@ -48,6 +48,21 @@ int pick_waves(int bh, int lq, int lk) {
     return lq % 256 == 0 ? 8 : 4;
 }
 
+// Which kernel serves a shape.  256-row query blocks go to the one-wave-per-SIMD kernel when an item
+// has at least three K/V tiles (its pipeline depth), otherwise to the 8-wave ring kernel; other row
+// counts to the 4-wave register-staged kernel.  FA_W64=0 / FA_RING=0 step down for A/B comparisons.
+enum KernelId { kKernelW64, kKernelRing, kKernelStaged8, kKernelStaged4 };
+const char* const kKernelNames[] = {"fa::fa_fwd_w64_kernel", "fa::fa_fwd_ring_kernel<8>", "fa::fa_fwd_kernel<8>",
+                                    "fa::fa_fwd_kernel<4>"};
+KernelId pick_kernel(int nw, int lk) {
+    if (nw != 8) return kKernelStaged4;
+    bool w64 = true, ring = true;
+    if (const char* e = std::getenv("FA_W64")) w64 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
+    if (w64 && lk >= 3 * fa::kKvTile) return kKernelW64;
+    return ring ? kKernelRing : kKernelStaged8;
+}
+
 // Compute units of the current device (cached per device id).
 int device_cus() {
     static int cached[64] = {0};
@@ -82,20 +97,20 @@ int launch(const fa::FwdParams& base, hipStream_t stream) {
     if (const char* e = std::getenv("FA_PERSISTENT"))
         if (std::atoi(e) == 0) grid = items;
     if (grid > items) grid = items;
-    // static LDS: ring kernel 96 KiB ring + 64 KiB staging images; register-staged kernel 64 KiB ring
-    // + 8 KiB staging image per wave
-    bool ring = true;
-    if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
-    bool w64 = false;
-    if (const char* e = std::getenv("FA_W64")) w64 = std::atoi(e) != 0;
-    if (nw == 8 && w64 && p.lk >= 3 * fa::kKvTile)
-        hipLaunchKernelGGL(fa::fa_fwd_w64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else if (nw == 8 && ring)
-        hipLaunchKernelGGL(fa::fa_fwd_ring_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
-    else if (nw == 8)
-        hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
-    else
-        hipLaunchKernelGGL(fa::fa_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    switch (pick_kernel(nw, p.lk)) {
+        case kKernelW64:
+            hipLaunchKernelGGL(fa::fa_fwd_w64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+            break;
+        case kKernelRing:
+            hipLaunchKernelGGL(fa::fa_fwd_ring_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+            break;
+        case kKernelStaged8:
+            hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+            break;
+        default:
+            hipLaunchKernelGGL(fa::fa_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+            break;
+    }
     FA_HIP(hipGetLastError());
     return FA_OK;
 }
@@ -126,6 +141,7 @@ extern "C" {
 const char* fa_last_error(void) { return g_last_error; }
 
 const char* fa_version(void) { return "flash_attention gfx950 0.1"; }
+const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(1, lq, lk), lk)]; }
 
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
                int D, int tile, void* stream_, float* elapsed_ms) {

@@ -110,6 +110,12 @@ const char* fa_last_error(void);
 /* Library version string. */
 const char* fa_version(void);
 
+/* Name of the device kernel that serves Lq query rows against Lk keys per head (as rocprofv3
+ * reports it, without template arguments' spelling differences); for benchmark records.  No
+ * counterpart in the reference, whose wrapper picks among seven instantiations of one kernel
+ * (flash_attention_tensor_cores/wrapper.cu:89-185). */
+const char* fa_kernel_name(int lq, int lk);
+
 #ifdef __cplusplus
 }
 #endif

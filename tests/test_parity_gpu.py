@@ -70,6 +70,45 @@ def test_both_workgroup_sizes(fa, oracle, torch_dev, nwaves, monkeypatch):
         gate(oracle, oracle.attention_cpu(Q, K, V), O, f"{shape} nwaves={nwaves}")
 
 
+@pytest.mark.parametrize("env,kernel", [
+    ({}, b"fa::fa_fwd_w64_kernel"),
+    ({"FA_W64": "0"}, b"fa::fa_fwd_ring_kernel<8>"),
+    ({"FA_W64": "0", "FA_RING": "0"}, b"fa::fa_fwd_kernel<8>"),
+])
+def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, monkeypatch):
+    """The launcher's three kernels for 256-row query blocks, each on: few tiles per item, several
+    items per workgroup (more items than CUs), rows whose maximum jumps from tile to tile, and
+    bit-identical results across the variants' common shapes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert fa.lib().fa_kernel_name(512, 512) == kernel
+    assert fa.lib().fa_kernel_name(256, 128) != b"fa::fa_fwd_w64_kernel"  # needs three tiles per item
+    assert fa.lib().fa_kernel_name(320, 320) == b"fa::fa_fwd_kernel<4>"
+    for shape in [(1, 1, 256, 128), (2, 3, 768, 128), (1, 9, 1280, 128)]:
+        Q, K, V = normal_fp16(21, shape)
+        O = run_dev(fa, torch_dev, Q, K, V)
+        gate(oracle, oracle.attention_cpu(Q, K, V), O, f"{shape} {kernel}")
+    # 40*16 heads x 1 block = 640 items on 256 CUs: two or three items per workgroup, 4 tiles each
+    shape = (40, 16, 256, 128)
+    Q, K, V = normal_fp16(22, shape)
+    O = run_dev(fa, torch_dev, Q, K, V)
+    for b, h in [(0, 0), (17, 5), (39, 15)]:
+        ref = oracle.attention_cpu(Q[b:b + 1, h:h + 1], K[b:b + 1, h:h + 1], V[b:b + 1, h:h + 1])
+        gate(oracle, ref, O[b:b + 1, h:h + 1], f"{shape} slice {(b, h)} {kernel}")
+    assert np.isfinite(O.astype(np.float32)).all()
+    # a dominating key in every tile, growing from tile to tile: a rescale per tile in both sub-blocks
+    rng = np.random.default_rng(23)
+    shape = (1, 2, 512, 128)
+    Q = (rng.standard_normal(shape) * 2).astype(np.float16)
+    K = (rng.standard_normal(shape) * 2).astype(np.float16)
+    V = rng.standard_normal(shape).astype(np.float16)
+    for t in range(8):
+        for row in (3, 40, 70, 200, 255, 300, 511):
+            K[:, :, 64 * t + (row % 64), :] = (Q[:, :, row, :].astype(np.float32) * (0.15 + 0.08 * t)).astype(np.float16)
+    O = run_dev(fa, torch_dev, Q, K, V)
+    gate(oracle, oracle.attention_cpu(Q, K, V), O, f"spiked {kernel}")
+
+
 def test_testing_recipe_bias_and_large_scores(fa, oracle, torch_dev):
     """Inputs with a mean (testing.cu:160) and with large dot products: the running max has to
     move a lot between tiles."""
