@@ -335,10 +335,17 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
 #ifndef W64_ABLATE_VEC  // (timing experiments only: wrong results)
             static_for<n_new>([&](auto jc) {
                 constexpr int e = n_done + decltype(jc)::value;
+#ifdef W64_ABLATE_FMA  // (timing experiments only: wrong results)
+                if constexpr (e < 16)
+                    sy0[e] = __builtin_amdgcn_exp2f(sy0[e]);
+                else
+                    sy1[e - 16] = __builtin_amdgcn_exp2f(sy1[e - 16]);
+#else
                 if constexpr (e < 16)
                     sy0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sy0[e], c, nm));
                 else
                     sy1[e - 16] = __builtin_amdgcn_exp2f(__builtin_fmaf(sy1[e - 16], c, nm));
+#endif
             });
             // elements [n_prev, n_done) got their exponential in the previous gap
             static_for<n_done - n_prev>([&](auto jc) {
@@ -466,8 +473,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     const float c = p.scale_log2e;
     constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
 
-    // ---- load cursors (element offsets into K and V): the tile the next transfer fetches.  K runs
-    //      three tiles ahead of the compute stream, V two; past the end of the stream they stay on the
+    // ---- load cursor (an element offset common to K and V): the tile the next K transfer fetches.  It
+    //      runs three tiles ahead of the compute stream; the V transfer of a step fetches the tile the
+    //      K transfer of the step before fetched.  Past the end of the stream the cursor stays on the
     //      last tile (redundant transfers into slots nobody reads any more).
     struct Cursor {
         int item, tile;
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     };
 #define W64_ADVANCE(cur_)                                                                      \
     do {                                                                                       \
-        if ((cur_).tile + 1 < n_tiles) {                                                       \
+        if (__builtin_expect((cur_).tile + 1 < n_tiles, 1)) {                                  \
             ++(cur_).tile;                                                                     \
             (cur_).off += kTileElems;                                                          \
         } else if ((cur_).item + stride < n_items) {                                           \
@@ -494,17 +502,15 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         dma_piece_at<1024>(t_, d_koff[1]);                                                     \
         dma_piece_at<2048>(t_, d_koff[2]);                                                     \
         dma_piece_at<3072>(t_, d_koff[3]);                                                     \
-        W64_ADVANCE(kc);                                                                       \
     } while (0)
 #define W64_DMA_V(slot_)                                                                       \
     do {                                                                                       \
-        const half_t* t_ = p.v + vc.off;                                                       \
+        const half_t* t_ = p.v + kc.off;                                                       \
         dma_set_base(v_lds + (unsigned)(slot_) * (unsigned)kTileBytes + d_piece);              \
         dma_piece_at<0>(t_, d_voff);                                                           \
         dma_piece_at<1024>(t_, d_voff);                                                        \
         dma_piece_at<2048>(t_, d_voff);                                                        \
         dma_piece_at<3072>(t_, d_voff);                                                        \
-        W64_ADVANCE(vc);                                                                       \
     } while (0)
 
     // ---- compute stream: first item
@@ -513,14 +519,17 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     decode_item(p, item, head, qb);
     size_t wrow = (size_t)head * p.lq + (size_t)qb * QB + wave * 64;  // this wave's first query row
     Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
-    Cursor vc = kc;
 
     // ---- prologue: K(0..2), V(0..1), the first item's Q rows
     W64_DMA_K(0);
-    W64_DMA_K(1);
-    W64_DMA_K(2);
     W64_DMA_V(0);
+    W64_ADVANCE(kc);
+    W64_DMA_K(1);
     W64_DMA_V(1);
+    W64_ADVANCE(kc);
+    W64_DMA_K(2);
+    size_t v_next_off = kc.off;  // V(2): what step 0 transfers
+    W64_ADVANCE(kc);
     dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
     dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
     wait_all_vmem();
@@ -592,11 +601,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 
         // ---- this step's transfers, issued piece by piece inside phase 1: K(t+3), V(t+2)
         const half_t* k_src = p.k + kc.off;
-        const half_t* v_src = p.v + vc.off;
+        const half_t* v_src = p.v + v_next_off;
+        v_next_off = kc.off;
         const unsigned k_dst = k_lds + (unsigned)(SC * kTileBytes) + d_piece;
         const unsigned v_dst = v_lds + (unsigned)(SC2 * kTileBytes) + d_piece;
         W64_ADVANCE(kc);
-        W64_ADVANCE(vc);
         // pieces 0-3: K, 4-7: V
         auto dma_step = [&](auto jc) {
 #ifndef W64_ABLATE_DMA  // (timing experiments only: wrong results)

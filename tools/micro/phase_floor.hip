@@ -28,11 +28,11 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, const half_
         f32x16 z[4] = {};
         acc_store<kAccA>(z);
         acc_store<kAccB>(z);
-        static_for<64>([&](auto ic) { acc_put_u32<128 + decltype(ic)::value>(0u); });
+        static_for<128>([&](auto ic) { acc_put_u32<128 + decltype(ic)::value>(0u); });
     }
     f32x16 sa0 = {}, sa1 = {}, sb0 = {}, sb1 = {};
     half8 pa[4] = {}, pb[4] = {};
-    half8 ka0[W64_K_AHEAD] = {}, ka1[W64_K_AHEAD] = {};
+    half8 ka0[8] = {}, ka1[8] = {};
     float mx_a = 0, mx_b = 0, la = 0, lb = 0, ma = 0, mb = 0;
     lane_mask_t need_a = 0, need_b = 0;
     const unsigned d_off = (unsigned)(lane * 16);
@@ -47,17 +47,17 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, const half_
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if constexpr (MODE == 0 || MODE == 1 || MODE == 2) {
-            fused_phase<kAccB, kQregB, 0, kTileBytes, kTileBytes>(w, ka0, ka1, sb0, sb1, pb, mx_b, mb, need_b, sa0, sa1, ma, la, pa, 0.001f, dma_none);
+            fused_phase<true, kAccB, kQregB, kTileBytes, 0>(w, ka0, ka1, sb0, sb1, pb, mx_b, mb, need_b, sa0, sa1, ma, la, pa, 0.001f, dma_none);
             if constexpr (MODE >= 1) { RowState r{mb, mb, lb}; rescale_if_needed<kAccB>(need_b, mx_b, r); mb = r.m_run; lb = r.l_run; }
-            fused_phase<kAccA, kQregA, kTileBytes, 0, kTileBytes>(w, ka0, ka1, sa0, sa1, pa, mx_a, ma, need_a, sb0, sb1, mb, lb, pb, 0.001f, dma_none);
+            fused_phase<false, kAccA, kQregA, 0, 0>(w, ka0, ka1, sa0, sa1, pa, mx_a, ma, need_a, sb0, sb1, mb, lb, pb, 0.001f, dma_none);
             if constexpr (MODE >= 1) { RowState r{ma, ma, la}; rescale_if_needed<kAccA>(need_a, mx_a, r); ma = r.m_run; la = r.l_run; }
             if constexpr (MODE >= 2) __syncthreads();
         } else {
-            fused_phase<kAccB, kQregB, 0, kTileBytes, kTileBytes>(w, ka0, ka1, sb0, sb1, pb, mx_b, mb, need_b, sa0, sa1, ma, la, pa, 0.001f, dma_step);
+            fused_phase<true, kAccB, kQregB, kTileBytes, 0>(w, ka0, ka1, sb0, sb1, pb, mx_b, mb, need_b, sa0, sa1, ma, la, pa, 0.001f, dma_step);
             { RowState r{mb, mb, lb}; rescale_if_needed<kAccB>(need_b, mx_b, r); mb = r.m_run; lb = r.l_run; }
-            fused_phase<kAccA, kQregA, kTileBytes, 0, kTileBytes>(w, ka0, ka1, sa0, sa1, pa, mx_a, ma, need_a, sb0, sb1, mb, lb, pb, 0.001f, dma_none);
+            fused_phase<false, kAccA, kQregA, 0, 0>(w, ka0, ka1, sa0, sa1, pa, mx_a, ma, need_a, sb0, sb1, mb, lb, pb, 0.001f, dma_none);
             { RowState r{ma, ma, la}; rescale_if_needed<kAccA>(need_a, mx_a, r); ma = r.m_run; la = r.l_run; }
-            wait_all_vmem();
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __syncthreads();
         }
     }
