@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Build-time audit of fa_fwd_w64_kernel, whose inline asm owns the accumulator registers.
+
+The kernel names a[0:255] literally in its instruction strings; the compiler does not know they hold
+live values.  That is only sound while the compiler itself uses no accumulator register and spills
+nothing in that kernel.  This script compiles the library's device code to assembly and fails if
+the kernel has scratch, spills, or any v_accvgpr_* / a[..] operand outside the #ASMSTART/#ASMEND
+blocks.
+
+    python tools/check_owned_regs.py [extra hipcc flags...]
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "flash-attention_amd", "csrc", "flash_attention_capi.hip")
+KERNEL = "_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE"
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "capi.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-honor-nans", "-S",
+               "--cuda-device-only", "-o", out, SRC] + sys.argv[1:]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    m = re.search(r"^" + KERNEL + r":.*?\n\s*s_endpgm", text, re.S | re.M)
+    if not m:
+        sys.exit("check_owned_regs: kernel not found in the assembly")
+    problems = []
+    in_asm = False
+    for line in m.group(0).split("\n"):
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        code = line.split(";")[0]
+        if not in_asm and (re.search(r"\bv_accvgpr", code) or re.search(r"\ba\[?\d", code)):
+            problems.append("compiler-generated accumulator-register access: " + code.strip())
+        if re.search(r"\bscratch_(load|store)", code):
+            problems.append("scratch access: " + code.strip())
+    meta = text[text.find(".amdhsa_kernel " + KERNEL):]
+    meta = meta[:meta.find(".end_amdhsa_kernel")]
+    for key in (".amdhsa_private_segment_fixed_size",):
+        mm = re.search(key + r"\s+(\d+)", meta)
+        if mm and int(mm.group(1)) != 0:
+            problems.append(f"{key} = {mm.group(1)}")
+    if problems:
+        print("check_owned_regs: FAILED for", KERNEL)
+        for p in problems[:20]:
+            print("   ", p)
+        sys.exit(1)
+    print("check_owned_regs: ok (no spills, no scratch, no compiler use of accumulator registers)")
+
+
+if __name__ == "__main__":
+    main()
