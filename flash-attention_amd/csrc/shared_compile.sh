@@ -10,3 +10,4 @@ OUT_LIB=${OUT_LIB:-libflash_attention.so}
     -Wall -Wno-unused-result \
     -o "$OUT_LIB" flash_attention_capi.hip
 echo "built $OUT_LIB"
+python3 ../../tools/check_owned_regs.py
