@@ -168,14 +168,18 @@ __device__ __forceinline__ void acc_put_u32(unsigned x) {
 // s_nop separates the last write from an MFMA that reads it.
 template <int QBASE>
 __device__ __forceinline__ void q_install(const char* img_half, int lane) {
-    half8 qf[8];
-    fetch_q_frags(qf, img_half, lane);
-    static_for<32>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const u32x4 wds = __builtin_bit_cast(u32x4, qf[i >> 2]);
-        acc_put_u32<QBASE + i>(wds[i & 3]);
+    lane = opaque(lane);
+    const int r = lane & 31, hh = lane >> 5;
+    // lane (r, hh) takes chunk 2ks + hh of row r; the image's slot of chunk c in row r is c ^ (r & 15),
+    // i.e. ((2ks) ^ (r & 14)) plus a lane-constant low bit: k-step ks sits at base ^ (ks << 5)
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)img_half +
+                          (unsigned)(r * kRowBytes + ((hh ^ (r & 15)) << 4));
+    static_for<8>([&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        const unsigned addr = base ^ (unsigned)(ks << 5);
+        asm volatile("ds_read_b128 a[%1:%2], %0" : : "v"(addr), "n"(QBASE + 4 * ks), "n"(QBASE + 4 * ks + 3) : "memory");
     });
-    asm volatile("s_nop 3");
+    lds_wait_all();
 }
 // whole sub-block accumulator <-> values (item boundaries only)
 template <int BASE>
@@ -191,6 +195,17 @@ __device__ __forceinline__ void acc_store(const f32x16 (&o)[4]) {
     static_for<64>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         acc_put<BASE + i>(o[i >> 4][i & 15]);
+    });
+}
+// a[BASE : BASE+63] = 0 through the matrix pipe (four MFMAs of zero operands with C = 0)
+template <int BASE>
+__device__ __forceinline__ void acc_zero() {
+    half8 z = {};
+    asm volatile("" : "+v"(z));
+    static_for<4>([&](auto ic) {
+        constexpr int LO = BASE + 16 * decltype(ic)::value;
+        const half8 zz = z;
+        asm volatile("v_mfma_f32_32x32x16_f16 a[%1:%2], %0, %0, 0" : : "v"(zz), "n"(LO), "n"(LO + 15));
     });
 }
 template <int BASE>
@@ -580,11 +595,22 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         else                                                                                   \
             store_output_rows(p.o + (row_) * kHeadDim, (img_), lane, o_, (st_).l_run);         \
     } while (0)
-#define W64_INIT(base_, st_, row_)                                                             \
+    // Start of an item for one sub-block, given the scaled row max mx_ of its first tile.  A fresh item
+    // takes that max as its reference at once (nothing to rescale: O = 0, l = 0); a continued one
+    // (blockwise mode) loads its state and decides as for any other tile.  Sets need_ accordingly.
+#define W64_INIT(base_, st_, row_, mx_, need_)                                                 \
     do {                                                                                       \
-        f32x16 o_[4];                                                                          \
-        init_state(p, (row_) + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);         \
-        acc_store<base_>(o_);                                                                  \
+        if (p.flags & kFlagLoadState) {                                                        \
+            f32x16 o_[4];                                                                      \
+            init_state(p, (row_) + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);     \
+            acc_store<base_>(o_);                                                              \
+            need_ = rescale_needed(mx_, (st_).m_run);                                          \
+        } else {                                                                               \
+            acc_zero<base_>();                                                                 \
+            (st_).m_run = (st_).m_true = (mx_);                                                \
+            (st_).l_run = 0.0f;                                                                \
+            need_ = 0;                                                                         \
+        }                                                                                      \
     } while (0)
 
     // One step.  Tile j of either ring lives in slot j % 3; SC = t % 3.  Phase 1 re-fills the fragment
@@ -643,8 +669,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if (b_started) W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
             out_b = wrow;
             b_started = true;
-            W64_INIT(kAccB, rb, wrow + 32);
-            need_b = rescale_needed(mx_b, rb.m_run);
+            W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b);
         }
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
 
@@ -671,8 +696,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 return true;
             }
             out_a = nwrow;
-            W64_INIT(kAccA, ra, nwrow);
-            need_a = rescale_needed(mx_a, ra.m_run);
+            W64_INIT(kAccA, ra, nwrow, mx_a, need_a);
         }
         rescale_if_needed<kAccA>(need_a, mx_a, ra);
 
