@@ -201,7 +201,7 @@ __device__ __forceinline__ void acc_store(const f32x16 (&o)[4]) {
 template <int BASE>
 __device__ __forceinline__ void acc_zero() {
     half8 z = {};
-    asm volatile("" : "+v"(z));
+    asm volatile("s_nop 3" : "+v"(z));  // wait states between the vector writes of z and the MFMAs reading it
     static_for<4>([&](auto ic) {
         constexpr int LO = BASE + 16 * decltype(ic)::value;
         const half8 zz = z;

@@ -109,6 +109,34 @@ def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, monkeypatch):
     gate(oracle, oracle.attention_cpu(Q, K, V), O, f"spiked {kernel}")
 
 
+def test_result_does_not_depend_on_what_ran_before(fa, oracle, torch_dev):
+    """Registers and LDS keep the previous launch's contents: a kernel that reads anything it has
+    not written itself gives results that depend on the launch before.  The same inputs are run
+    after a launch on large random values and after a launch on infinities and NaNs."""
+    import torch
+
+    shape = (16, 16, 1024, 128)  # four items per workgroup on 256 CUs
+    n = int(np.prod(shape))
+    q = torch.empty(shape, dtype=torch.float16, device=torch_dev)
+    k, v = torch.empty_like(q), torch.empty_like(q)
+    fa.init_half(q, 1234), fa.init_half(k, 2345), fa.init_half(v, 3456)
+    g = torch.Generator(device=torch_dev).manual_seed(5)
+    noise = [torch.randn(n, generator=g, device=torch_dev).mul(50).to(torch.float16).view(shape) for _ in range(3)]
+    poison = [torch.full(shape, float("nan"), dtype=torch.float16, device=torch_dev) for _ in range(3)]
+    first = fa.attention(q, k, v).clone()
+    fa.attention(*noise)
+    second = fa.attention(q, k, v).clone()
+    fa.attention(*poison)
+    third = fa.attention(q, k, v).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(first.float()).all()
+    assert torch.equal(first, second), "result changed after a launch on other data"
+    assert torch.equal(first, third), "result changed after a launch on NaN data"
+    O = first[3:4, 5:6].cpu().numpy()
+    ref = oracle.attention_cpu(q[3:4, 5:6].cpu().numpy(), k[3:4, 5:6].cpu().numpy(), v[3:4, 5:6].cpu().numpy())
+    gate(oracle, ref, O, "slice (3,5) of the pattern workload")
+
+
 def test_testing_recipe_bias_and_large_scores(fa, oracle, torch_dev):
     """Inputs with a mean (testing.cu:160) and with large dot products: the running max has to
     move a lot between tiles."""
