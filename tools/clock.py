@@ -46,6 +46,8 @@ s = stamps.cpu().numpy().reshape(-1, 4)[:256]
 s = s[s[:, 3] > 0]
 clk = (s[:, 2] - s[:, 0]) / np.maximum(s[:, 3] - s[:, 1], 1) * 100.0
 dur = (s[:, 3] - s[:, 1]) / 100.0
+span = (s[:, 3].max() - s[:, 1].min()) / 100.0
+spread = (s[:, 1].max() - s[:, 1].min()) / 100.0
 print(f"{sys.argv[1]} L={L} {data}: launch {ms.value*1e3:.1f} us; in-kernel {np.median(dur):.1f} us; "
       f"shader clock median {np.median(clk):.0f} MHz (min {clk.min():.0f}, max {clk.max():.0f}); "
-      f"cycles per workgroup {np.median(s[:,2]-s[:,0]):.0f}")
+      f"cycles per workgroup {np.median(s[:,2]-s[:,0]):.0f}; first entry to last exit {span:.1f} us, entries spread over {spread:.1f} us")
