@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--env", nargs="*", default=[], help="extra variants: KEY=VAL[,KEY=VAL] applied to every lib")
     ap.add_argument("--shapes", nargs="+", type=int, default=[512, 1024, 2048, 4096, 8192, 16384])
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--preheat", type=float, default=1.0,
+                    help="seconds of untimed launches per shape before timing (the chip's clock needs sustained load to settle)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--data", choices=["pattern", "normal"], default="pattern",
@@ -80,6 +82,13 @@ def main():
             for _ in range(5):
                 launch(i, B, L)
         torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.preheat:
+            for i in range(len(variants)):
+                for _ in range(25):
+                    launch(i, B, L)
+            torch.cuda.synchronize()
         for _ in range(args.rounds):
             for i in range(len(variants)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
