@@ -6,7 +6,7 @@ cd "$(dirname "${BASH_SOURCE[0]}")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_$$
 rm -rf "$OUT"; mkdir -p "$OUT"
-timeout -s KILL 240 rocprofv3 --pmc $@ --output-format csv -d "$OUT" -- python3 bench.py --seq-len "$L" --steps 20 --warmup 5 --no-cpu-baseline --no-sweep > "$OUT/log.txt" 2>&1 || { tail -5 "$OUT/log.txt"; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc $@ --output-format csv -d "$OUT" -- python3 bench.py --seq-len "$L" --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --preheat-seconds 0 > "$OUT/log.txt" 2>&1 || { tail -5 "$OUT/log.txt"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*_counter_collection.csv")[0]

@@ -56,7 +56,8 @@ def main():
     read_b = 2.0 * fetch["FETCH_SIZE"] * 1024.0
     write_b = write["WRITE_SIZE"] * 1024.0
     out = {
-        "command": f"rocprofv3 ... -- python3 bench.py --seq-len {L} --steps 20 --warmup 5 --no-cpu-baseline --no-sweep",
+        "command": f"tools/profile.sh {L} STEPS: rocprofv3 --kernel-trace --stats -- python3 bench.py --seq-len {L} --steps STEPS "
+                   "--warmup 5 --no-cpu-baseline --no-sweep; counter passes (--pmc, one per run) add --preheat-seconds 0",
         "workload": f"B={B} H={H} L={L} D={D}",
         "kernel": kern["Name"],
         "launches": int(kern["Calls"]),
