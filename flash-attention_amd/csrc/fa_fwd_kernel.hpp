@@ -388,7 +388,10 @@ __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int
 #ifdef FA_ABLATE_NO_STORE
         asm volatile("" ::"v"(v[i]));
 #else
-        *reinterpret_cast<u32x4*>(wr + i * 4 * kHeadDim) = v[i];
+        // streaming store: a plain store leaves the output dirty in the L2 (32 MiB across the chip, half of
+        // a 64 MiB output), and the write-back at the end of the kernel then delays the next launch
+        // (measured at L=512: 6.7 us between consecutive launches, 4.6 us with these)
+        __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(wr + i * 4 * kHeadDim));
 #endif
     }
 }

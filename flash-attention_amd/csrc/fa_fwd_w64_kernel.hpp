@@ -32,8 +32,10 @@
 //
 // Items (head, 256-row query block) form one stream of tiles per workgroup, as in the other
 // kernels.  The next item's Q rows are DMAed into the wave's 16 KiB staging image during the item's
-// last-but-one step; A picks its fragments up before phase 2 of the last step (which already
-// computes S_A of the next item), B before phase 1 of the next step.  A sub-block's output is
+// last-but-one step; the fragment reads into the Q registers are requested one phase before the
+// registers are needed and complete behind that phase (A's during phase 1 of the last step, for
+// phase 2, which already computes S_A of the next item; B's during that phase 2, for phase 1 of the
+// next step).  A sub-block's output is
 // written out (through its half of the image, as whole rows) right after the phase that finished
 // it.  The kernel needs lq % 256 == 0 and at least 3 tiles per item; the launcher sends other
 // shapes to the other kernels.
@@ -164,10 +166,12 @@ template <int R>
 __device__ __forceinline__ void acc_put_u32(unsigned x) {
     asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(x), "n"(R));
 }
-// Q fragments of one sub-block: staging image -> registers -> a[QBASE : QBASE+31].  The trailing
-// s_nop separates the last write from an MFMA that reads it.
+// Q fragments of one sub-block: staging image -> a[QBASE : QBASE+31].  The reads are hidden from the
+// compiler like vbuf_read: lds_wait_all() stands between them and the first MFMA that takes the
+// registers.  q_install_issue alone lets a whole phase pass in between (a sub-block's Q registers
+// are idle while the other sub-block is on the matrix side), which hides the reads' latency.
 template <int QBASE>
-__device__ __forceinline__ void q_install(const char* img_half, int lane) {
+__device__ __forceinline__ void q_install_issue(const char* img_half, int lane) {
     lane = opaque(lane);
     const int r = lane & 31, hh = lane >> 5;
     // lane (r, hh) takes chunk 2ks + hh of row r; the image's slot of chunk c in row r is c ^ (r & 15),
@@ -179,6 +183,10 @@ __device__ __forceinline__ void q_install(const char* img_half, int lane) {
         const unsigned addr = base ^ (unsigned)(ks << 5);
         asm volatile("ds_read_b128 a[%1:%2], %0" : : "v"(addr), "n"(QBASE + 4 * ks), "n"(QBASE + 4 * ks + 3) : "memory");
     });
+}
+template <int QBASE>
+__device__ __forceinline__ void q_install(const char* img_half, int lane) {
+    q_install_issue<QBASE>(img_half, lane);
     lds_wait_all();
 }
 // whole sub-block accumulator <-> values (item boundaries only)
@@ -658,10 +666,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         }
 
         // ---- phase 1: matrix side B (S_B(t), O_B += V(t-1).P_B(t-1)), vector side A
-        if (first && b_started) {
-            // B starts a new item with this phase's scores; its Q rows arrived a step ago
-            q_install<kQregB>(img + 32 * kRowBytes, lane);
-        }
+        // In an item's last step A's next Q fragments are requested here: Q_A is idle while B is on the
+        // matrix side, and the rows arrived with the previous step's end-of-step wait.
+        if (last && more_items) q_install_issue<kQregA>(img, lane);
         fused_phase<true, kAccB, kQregB, SC1 * kTileBytes, SC * kTileBytes>(
             w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
         if (first) {
@@ -674,7 +681,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
 
         // ---- phase 2: matrix side A (S_A(t+1), O_A += V(t).P_A(t)), vector side B
-        if (last && more_items) q_install<kQregA>(img, lane);  // S_A(t+1) belongs to the next item
+        // In the last step S_A(t+1) belongs to the next item: Q_A must be complete.  B's next fragments are
+        // requested now (Q_B is idle in phase 2, whose own wait in gap 16 covers them).
+        if (last && more_items) {
+            lds_wait_all();
+            q_install_issue<kQregB>(img + 32 * kRowBytes, lane);
+        }
         fused_phase<false, kAccA, kQregA, 0, 0>(
             w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
         if (last) {
@@ -702,7 +714,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 
         // ---- end of step
 #ifndef W64_ABLATE_BARRIER  // (timing experiments only: wrong results)
-        // everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows
+        // Everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows.  (Loads
+        // complete in order among themselves; stores may overtake them, which only makes this wait longer.)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
 #endif
