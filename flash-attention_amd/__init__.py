@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "fa_forward",
     "fa_forward_host_half",
     "fa_forward_block",
+    "fa_forward_general",
     "fa_init_half",
     "fa_device_info",
     "fa_last_error",
@@ -70,6 +71,8 @@ def lib() -> ct.CDLL:
             [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 6 + [ct.c_void_p]
         )
         L.fa_forward_block.restype = ct.c_int
+        L.fa_forward_general.argtypes = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
+        L.fa_forward_general.restype = ct.c_int
         L.fa_init_half.argtypes = [HalfPtr, ct.c_size_t, ct.c_ulonglong, ct.c_void_p]
         L.fa_init_half.restype = ct.c_int
         L.fa_device_info.argtypes = [ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_double)]
@@ -151,6 +154,36 @@ def attention(q, k, v, out=None, tile: int = 64, stream=None, timed: bool = Fals
         rc = lib().fa_forward(
             _dev_half_ptr(q), _dev_half_ptr(k), _dev_half_ptr(v), _dev_half_ptr(out), B, H, L, D, tile,
             _stream_handle(stream), ct.byref(ms) if timed else None,
+        )
+    _check(rc)
+    return (out, float(ms.value)) if timed else out
+
+
+FLAG_CAUSAL = 1  # FA_FLAG_CAUSAL
+
+
+def attention_general(q, k, v, causal: bool = False, out=None, stream=None, timed: bool = False):
+    """``fa_forward_general``: q [B,H,Lq,D] against k, v [B,H,Lk,D], any Lq, Lk >= 1; ``causal``
+    applies the mask of the reference's CPU baseline (testing.cu:74-77; needs Lq == Lk).
+    Contiguous fp16 GPU tensors.  Returns ``out`` (and the kernel-only milliseconds when ``timed``)."""
+    import torch
+
+    for t in (q, k, v):
+        if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+            raise ValueError("q, k, v must be contiguous float16 GPU tensors; there is no CPU fallback")
+    B, H, Lq, D = q.shape
+    Lk = k.shape[2]
+    if k.shape != (B, H, Lk, D) or v.shape != k.shape:
+        raise ValueError("k, v must be [B,H,Lk,D] with q's B, H, D")
+    if out is None:
+        out = torch.empty_like(q)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device)
+    ms = ct.c_float(0.0)
+    with torch.cuda.device(q.device):
+        rc = lib().fa_forward_general(
+            _dev_half_ptr(q), _dev_half_ptr(k), _dev_half_ptr(v), _dev_half_ptr(out), B, H, Lq, Lk, D,
+            FLAG_CAUSAL if causal else 0, _stream_handle(stream), ct.byref(ms) if timed else None,
         )
     _check(rc)
     return (out, float(ms.value)) if timed else out

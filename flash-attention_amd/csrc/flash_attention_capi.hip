@@ -16,6 +16,7 @@
 #include "fa_fwd_kernel.hpp"
 #include "fa_fwd_ring_kernel.hpp"
 #include "fa_fwd_w64_kernel.hpp"
+#include "fa_fwd_general_kernel.hpp"
 
 namespace {
 
@@ -115,6 +116,35 @@ int launch(const fa::FwdParams& base, hipStream_t stream) {
     return FA_OK;
 }
 
+// Runs `launch_fn` on `stream`; with elapsed_ms non-null the launch is bracketed by events and waited for.
+template <typename F>
+int timed_launch(hipStream_t stream, float* elapsed_ms, F&& launch_fn) {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (elapsed_ms) {
+        FA_HIP(hipEventCreate(&ev0));
+        FA_HIP(hipEventCreate(&ev1));
+        FA_HIP(hipEventRecord(ev0, stream));
+    }
+    int rc = launch_fn();
+    if (elapsed_ms) {
+        if (rc == FA_OK) {
+            hipError_t e = hipEventRecord(ev1, stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ev1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+            if (e != hipSuccess) {
+                std::snprintf(g_last_error, sizeof(g_last_error), "event timing failed: %s", hipGetErrorString(e));
+                rc = FA_ERR_RUNTIME;
+            } else {
+                *elapsed_ms = ms;
+            }
+        }
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    return rc;
+}
+
 int validate(int B, int H, int L, int D, int tile) {
     if (tile != 64) return fail(FA_ERR_TILE, "run_tensor_flash_attention: tile must be 64%s");
     if (D != fa::kHeadDim) return fail(FA_ERR_HEAD_DIM, "run_tensor_flash_attention: D must be 128%s");
@@ -160,31 +190,43 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
     p.lk = L;
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
     p.flags = 0;
+    return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream); });
+}
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (elapsed_ms) {
-        FA_HIP(hipEventCreate(&ev0));
-        FA_HIP(hipEventCreate(&ev1));
-        FA_HIP(hipEventRecord(ev0, stream));
-    }
-    int rc = launch(p, stream);
-    if (elapsed_ms) {
-        if (rc == FA_OK) {
-            hipError_t e = hipEventRecord(ev1, stream);
-            if (e == hipSuccess) e = hipEventSynchronize(ev1);
-            float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-            if (e != hipSuccess) {
-                std::snprintf(g_last_error, sizeof(g_last_error), "event timing failed: %s", hipGetErrorString(e));
-                rc = FA_ERR_RUNTIME;
-            } else {
-                *elapsed_ms = ms;
-            }
-        }
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
-    }
-    return rc;
+int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
+                       int Lq, int Lk, int D, int flags, void* stream_, float* elapsed_ms) {
+    g_last_error[0] = 0;
+    if (D != fa::kHeadDim) return fail(FA_ERR_HEAD_DIM, "fa_forward_general: D must be 128%s");
+    if (Lq <= 0 || Lk <= 0) return fail(FA_ERR_SEQLEN, "fa_forward_general: Lq and Lk must be positive%s");
+    if (flags & ~FA_FLAG_CAUSAL) return fail(FA_ERR_SHAPE, "fa_forward_general: unknown flag%s");
+    if ((flags & FA_FLAG_CAUSAL) && Lq != Lk)
+        return fail(FA_ERR_SEQLEN, "fa_forward_general: the causal mask needs Lq == Lk%s");
+    if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "fa_forward_general: B and H must be positive%s");
+    if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "fa_forward_general: B*H too large%s");
+    if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "fa_forward_general: null tensor pointer%s");
+    if (flags == 0 && Lq == Lk && Lq % fa::kKvTile == 0)
+        return fa_forward(dQ, dK, dV, dO, B, H, Lq, D, fa::kKvTile, stream_, elapsed_ms);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    fa::FwdParams p{};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.bh = B * H;
+    p.lq = Lq;
+    p.lk = Lk;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
+    constexpr int kWaves = 4, kBlockRows = kWaves * fa::kRowsPerWave;
+    p.q_blocks = (Lq + kBlockRows - 1) / kBlockRows;
+    const long items = (long)p.bh * p.q_blocks;
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "fa_forward_general: grid size out of range%s");
+    return timed_launch(stream, elapsed_ms, [&]() -> int {
+        hipLaunchKernelGGL(fa::fa_fwd_general_kernel<kWaves>, dim3((unsigned)items), dim3(kWaves * 64), 0, stream, p);
+        FA_HIP(hipGetLastError());
+        return FA_OK;
+    });
 }
 
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,

@@ -1,0 +1,122 @@
+"""GPU tier: fa_forward_general (sequence lengths that are not a multiple of 64, Lq != Lk, the causal
+mask of attention_cpu, testing.cu:74-77) through the C ABI against the CPU oracle on identical fp16
+inputs.  Same gate as the other parity tests: max-abs <= 2e-3, relative L2 <= 1e-3."""
+import numpy as np
+import pytest
+
+from conftest import MAX_ABS_TOL, REL_L2_TOL, normal_fp16
+
+pytestmark = pytest.mark.gpu
+
+
+def gate(oracle, ref32, out16, what=""):
+    m = oracle.error_metrics(ref32, out16)
+    assert np.isfinite(out16.astype(np.float32)).all(), what
+    assert m["max_abs"] <= MAX_ABS_TOL and m["global_rel"] <= REL_L2_TOL, (what, m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def run_general(fa, dev, Q, K, V, causal=False):
+    """Inputs and output sit in buffers with a NaN / sentinel tail right behind them: a read past the
+    last key row would poison the result, a write past the last query row would change the tail."""
+    import torch
+
+    def padded(a, fill):
+        flat = torch.full((a.size + 4096,), fill, dtype=torch.float16, device=dev)
+        flat[: a.size] = torch.from_numpy(a).to(dev).reshape(-1)
+        return flat, flat[: a.size].view(*a.shape)
+
+    _, q = padded(Q, float("nan"))
+    _, k = padded(K, float("nan"))
+    _, v = padded(V, float("nan"))
+    o_flat, o = padded(np.zeros(Q.shape, np.float16), 123.0)
+    fa.attention_general(q, k, v, causal=causal, out=o)
+    torch.cuda.synchronize()
+    assert bool((o_flat[Q.size:] == 123.0).all()), "wrote past the last query row"
+    return o.cpu().numpy()
+
+
+@pytest.mark.parametrize("L", [1, 2, 31, 63, 65, 100, 127, 129, 200, 333, 777])
+def test_sequence_length_not_a_multiple_of_64(fa, oracle, dev, L):
+    Q, K, V = normal_fp16(100 + L, (2, 3, L, 128))
+    O = run_general(fa, dev, Q, K, V)
+    gate(oracle, oracle.attention_cpu(Q, K, V), O, f"L={L}")
+
+
+@pytest.mark.parametrize("L", [1, 5, 64, 65, 128, 200, 512, 1000])
+def test_causal_mask(fa, oracle, dev, L):
+    Q, K, V = normal_fp16(200 + L, (1, 3, L, 128))
+    O = run_general(fa, dev, Q, K, V, causal=True)
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, f"causal L={L}")
+
+
+def test_causal_first_row_is_first_value_row(fa, dev):
+    """Row 0 sees key 0 only: its output is V[0] exactly (p = 1, l = 1)."""
+    Q, K, V = normal_fp16(7, (1, 2, 130, 128))
+    O = run_general(fa, dev, Q, K, V, causal=True)
+    assert np.array_equal(O[:, :, 0], V[:, :, 0])
+
+
+@pytest.mark.parametrize("Lq,Lk", [(1, 500), (100, 64), (130, 1000), (512, 77), (64, 192), (257, 3)])
+def test_query_and_key_lengths_differ(fa, oracle, dev, Lq, Lk):
+    rng = np.random.default_rng(Lq * 1000 + Lk)
+    Q = rng.standard_normal((2, 2, Lq, 128), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((2, 2, Lk, 128), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((2, 2, Lk, 128), dtype=np.float32).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V)
+    st = oracle.BlockState(2, 2, Lq, 128)
+    oracle.block_update(st, Q, K, V)
+    gate(oracle, oracle.block_finalize(st), O, f"Lq={Lq} Lk={Lk}")
+
+
+def test_large_scores_with_tail_and_mask(fa, oracle, dev):
+    """Scores of a few hundred (biased inputs) with a ragged tail and the causal mask: the masked
+    entries must stay out of the row maximum and the rescale must fire."""
+    rng = np.random.default_rng(3)
+    shape = (1, 2, 333, 128)
+    Q, K = [(rng.standard_normal(shape, dtype=np.float32) * 2.0 + 0.5).astype(np.float16) for _ in range(2)]
+    V = rng.standard_normal(shape, dtype=np.float32).astype(np.float16)  # |O| stays where half an fp16 ulp < 2e-3
+    for causal in (False, True):
+        O = run_general(fa, dev, Q, K, V, causal=causal)
+        gate(oracle, oracle.attention_cpu(Q, K, V, causal=causal), O, f"large scores causal={causal}")
+
+
+def test_long_causal_row_subset(fa, oracle, dev):
+    L = 4096 + 40
+    Q, K, V = normal_fp16(9, (1, 2, L, 128))
+    O = run_general(fa, dev, Q, K, V, causal=True)
+    rows = np.unique(np.concatenate([np.arange(0, L, 97), [63, 64, 65, 127, 128, L - 2, L - 1]])).astype(np.int32)
+    ref = oracle.attention_cpu_rows(Q, K, V, rows, causal=True)
+    gate(oracle, ref, O[:, :, rows], "long causal rows")
+
+
+def test_tuned_shapes_are_passed_on(fa, dev):
+    """Lq == Lk, a multiple of 64, no mask: the same kernel as fa_forward, so the same bits."""
+    import torch
+
+    Q, K, V = normal_fp16(5, (2, 4, 512, 128))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    a = fa.attention(q, k, v)
+    b = fa.attention_general(q, k, v)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+def test_argument_errors(fa, dev):
+    import torch
+
+    q = torch.zeros((1, 1, 64, 128), dtype=torch.float16, device=dev)
+    k = torch.zeros((1, 1, 128, 128), dtype=torch.float16, device=dev)
+    with pytest.raises(fa.FlashAttentionError, match="causal mask needs Lq == Lk"):
+        fa.attention_general(q, k, k, causal=True)
+    q64 = torch.zeros((1, 1, 64, 64), dtype=torch.float16, device=dev)
+    with pytest.raises(fa.FlashAttentionError, match="D must be 128"):
+        fa.attention_general(q64, q64, q64)
