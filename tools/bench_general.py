@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Throughput of fa_forward_general (ragged lengths, causal mask) next to the tuned kernels.
+
+    python tools/bench_general.py
+
+Pattern data of the reference's throughput driver, 1 s of preheat, back-to-back launches between two
+events.  FLOPs: 4*B*H*Lq*Lk*D without mask, half of that (the visible triangle, diagonal included:
+2*B*H*L*(L+1)*D) with the causal mask."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+fa = ge.load_package()
+dev = torch.device("cuda:0")
+H, D = 16, 128
+n = 16384 * H * D + 4096
+buf = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(4)]
+for t, seed in zip(buf[:3], (1234, 2345, 3456)):
+    fa.init_half(t, seed)
+
+def run(label, B, L, causal, general=True, reps=20):
+    m = B * H * L * D
+    q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
+    f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * B * H * L * (L + 1) * D if causal else 4.0 * B * H * L * L * D
+    print(f"{label:44s} B={B:2d} L={L:5d}  {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s")
+
+for B, L in ((32, 512), (8, 2048), (1, 16384)):
+    run("tuned kernel, no mask", B, L, False, general=False)
+    run("general kernel, no mask, L-1 (ragged tail)", B, L - 1, False)
+    run("general kernel, causal", B, L, True)
+    run("general kernel, causal, L-1", B, L - 1, True)
