@@ -178,8 +178,9 @@ __device__ __forceinline__ void qk_tile(const char* kb, const LaneGeom& g, const
 // accumulator is skipped on most tiles.  On return s0/s1 hold p and pf the fp16 P^T fragments:
 // registers 8s..8s+7 of a 32-key block are k-step s of that block, element j of lane half hh being
 // key 16s + 8(j>>2) + 4hh + (j&3).
+template <int DB>  // DB: 32-column blocks of the output accumulator (head dim / 32)
 __device__ __forceinline__ void softmax_tile(f32x16& s0, f32x16& s1, float c, float& m_run, float& m_true,
-                                             float& l_run, f32x16 (&oacc)[4], half8 (&pf)[4]) {
+                                             float& l_run, f32x16 (&oacc)[DB], half8 (&pf)[4]) {
 #ifdef FA_ABLATE_SOFTMAX  // timing experiments only: wrong results
     pf[0] = pack_half8(s0, 0);
     pf[1] = pack_half8(s0, 8);
@@ -202,7 +203,7 @@ __device__ __forceinline__ void softmax_tile(f32x16& s0, f32x16& s1, float c, fl
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
     }

@@ -196,7 +196,7 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream_, float* elapsed_ms) {
     g_last_error[0] = 0;
-    if (D != fa::kHeadDim) return fail(FA_ERR_HEAD_DIM, "fa_forward_general: D must be 128%s");
+    if (D != 64 && D != 128 && D != 256) return fail(FA_ERR_HEAD_DIM, "fa_forward_general: D must be 64, 128 or 256%s");
     if (Lq <= 0 || Lk <= 0) return fail(FA_ERR_SEQLEN, "fa_forward_general: Lq and Lk must be positive%s");
     if (flags & ~FA_FLAG_CAUSAL) return fail(FA_ERR_SHAPE, "fa_forward_general: unknown flag%s");
     if ((flags & FA_FLAG_CAUSAL) && Lq != Lk)
@@ -204,7 +204,7 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "fa_forward_general: B and H must be positive%s");
     if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "fa_forward_general: B*H too large%s");
     if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "fa_forward_general: null tensor pointer%s");
-    if (flags == 0 && Lq == Lk && Lq % fa::kKvTile == 0)
+    if (flags == 0 && D == fa::kHeadDim && Lq == Lk && Lq % fa::kKvTile == 0)
         return fa_forward(dQ, dK, dV, dO, B, H, Lq, D, fa::kKvTile, stream_, elapsed_ms);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
@@ -223,7 +223,13 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     const long items = (long)p.bh * p.q_blocks;
     if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "fa_forward_general: grid size out of range%s");
     return timed_launch(stream, elapsed_ms, [&]() -> int {
-        hipLaunchKernelGGL(fa::fa_fwd_general_kernel<kWaves>, dim3((unsigned)items), dim3(kWaves * 64), 0, stream, p);
+        const dim3 grid((unsigned)items), block(kWaves * 64);
+        if (D == 64)
+            hipLaunchKernelGGL(fa::fa_fwd_general_kernel<64>, grid, block, 0, stream, p);
+        else if (D == 128)
+            hipLaunchKernelGGL(fa::fa_fwd_general_kernel<128>, grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL(fa::fa_fwd_general_kernel<256>, grid, block, 0, stream, p);
         FA_HIP(hipGetLastError());
         return FA_OK;
     });

@@ -94,12 +94,13 @@ int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
                      void* stream);
 
 /* General forward: any Lq >= 1 and Lk >= 1 (no multiple-of-64 rule, query and key lengths may
- * differ) and, with FA_FLAG_CAUSAL, the causal mask of the reference's CPU baseline
- * (attention_cpu's `causal` argument, testing.cu:41-48,74-77: key j > query i takes no part;
- * needs Lq == Lk).  The reference's GPU path has neither: its wrapper rejects L % 64 != 0
- * (wrapper.cu:59-61) and its kernel has no mask; README.md:44-47 lists both as future work.
- *   dQ, dO  [B][H][Lq][128] fp16        dK, dV  [B][H][Lk][128] fp16
- * Shapes the tuned kernels take (Lq == Lk, a multiple of 64, no flags) are passed on to
+ * differ), head dim D of 64, 128 or 256 and, with FA_FLAG_CAUSAL, the causal mask of the
+ * reference's CPU baseline (attention_cpu's `causal` argument, testing.cu:41-48,74-77: key
+ * j > query i takes no part; needs Lq == Lk).  The reference's GPU path has none of these: its
+ * wrapper rejects L % 64 != 0 (wrapper.cu:59-61), D is fixed at 128 (cuda_utils.cuh:11) and its
+ * kernel has no mask; README.md:44-47 lists them as future work.
+ *   dQ, dO  [B][H][Lq][D] fp16        dK, dV  [B][H][Lk][D] fp16        scale 1/sqrt(D)
+ * Shapes the tuned kernels take (D == 128, Lq == Lk, a multiple of 64, no flags) are passed on to
  * fa_forward.  Asynchronous on `stream` unless elapsed_ms is non-NULL (as fa_forward). */
 enum { FA_FLAG_CAUSAL = 1 };
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,

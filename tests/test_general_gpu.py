@@ -117,6 +117,28 @@ def test_argument_errors(fa, dev):
     k = torch.zeros((1, 1, 128, 128), dtype=torch.float16, device=dev)
     with pytest.raises(fa.FlashAttentionError, match="causal mask needs Lq == Lk"):
         fa.attention_general(q, k, k, causal=True)
-    q64 = torch.zeros((1, 1, 64, 64), dtype=torch.float16, device=dev)
-    with pytest.raises(fa.FlashAttentionError, match="D must be 128"):
-        fa.attention_general(q64, q64, q64)
+    q96 = torch.zeros((1, 1, 64, 96), dtype=torch.float16, device=dev)
+    with pytest.raises(fa.FlashAttentionError, match="D must be 64, 128 or 256"):
+        fa.attention_general(q96, q96, q96)
+
+
+@pytest.mark.parametrize("D", [64, 256])
+@pytest.mark.parametrize("L,causal", [(64, False), (100, False), (512, False), (777, False), (200, True), (640, True)])
+def test_other_head_dims(fa, oracle, dev, D, L, causal):
+    """D = 64 and 256 (the reference fixes 128, cuda_utils.cuh:11; the CPU baseline takes any D)."""
+    Q, K, V = normal_fp16(300 + D + L, (2, 2, L, D))
+    O = run_general(fa, dev, Q, K, V, causal=causal)
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=causal), O, f"D={D} L={L} causal={causal}")
+
+
+@pytest.mark.parametrize("D", [64, 256])
+def test_other_head_dims_rectangular(fa, oracle, dev, D):
+    rng = np.random.default_rng(D)
+    Lq, Lk = 130, 333
+    Q = rng.standard_normal((1, 3, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((1, 3, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((1, 3, Lk, D), dtype=np.float32).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V)
+    st = oracle.BlockState(1, 3, Lq, D)
+    oracle.block_update(st, Q, K, V)
+    gate(oracle, oracle.block_finalize(st), O, f"D={D} rectangular")

@@ -19,7 +19,7 @@ buf = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(4)]
 for t, seed in zip(buf[:3], (1234, 2345, 3456)):
     fa.init_half(t, seed)
 
-def run(label, B, L, causal, general=True, reps=20):
+def run(label, B, L, causal, general=True, reps=20, D=128):
     m = B * H * L * D
     q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
     f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))
@@ -36,10 +36,14 @@ def run(label, B, L, causal, general=True, reps=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * B * H * L * (L + 1) * D if causal else 4.0 * B * H * L * L * D
-    print(f"{label:44s} B={B:2d} L={L:5d}  {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s")
+    print(f"{label:44s} B={B:2d} L={L:5d} D={D:3d}  {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s")
 
 for B, L in ((32, 512), (8, 2048), (1, 16384)):
     run("tuned kernel, no mask", B, L, False, general=False)
     run("general kernel, no mask, L-1 (ragged tail)", B, L - 1, False)
     run("general kernel, causal", B, L, True)
     run("general kernel, causal, L-1", B, L - 1, True)
+for D_, shapes in ((64, ((8, 2048), (1, 8192))), (256, ((4, 2048), (1, 8192)))):
+    for B, L in shapes:
+        run("general kernel, no mask", B, L, False, D=D_)
+        run("general kernel, causal", B, L, True, D=D_)
