@@ -29,6 +29,9 @@ EXPORTED_SYMBOLS = (
     "fa_forward_host_half",
     "fa_forward_block",
     "fa_forward_general",
+    "fa_forward_general_host_half",
+    "run_naive_attention_host_half",
+    "run_cuda_cores_flash_attention_host_half",
     "fa_init_half",
     "fa_device_info",
     "fa_last_error",
@@ -73,6 +76,14 @@ def lib() -> ct.CDLL:
         L.fa_forward_block.restype = ct.c_int
         L.fa_forward_general.argtypes = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
         L.fa_forward_general.restype = ct.c_int
+        L.fa_forward_general_host_half.argtypes = L.fa_forward_general.argtypes
+        L.fa_forward_general_host_half.restype = ct.c_int
+        # the sibling libraries' symbols, with the argtypes the reference's caller declares
+        # (benchmarks/compare_impls.py:42-58)
+        L.run_naive_attention_host_half.argtypes = [HalfPtr] * 4 + [ct.c_int] * 5 + [ct.c_void_p, FloatPtr]
+        L.run_naive_attention_host_half.restype = None
+        L.run_cuda_cores_flash_attention_host_half.argtypes = [HalfPtr] * 4 + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
+        L.run_cuda_cores_flash_attention_host_half.restype = None
         L.fa_init_half.argtypes = [HalfPtr, ct.c_size_t, ct.c_ulonglong, ct.c_void_p]
         L.fa_init_half.restype = ct.c_int
         L.fa_device_info.argtypes = [ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_double)]
@@ -160,6 +171,23 @@ def attention(q, k, v, out=None, tile: int = 64, stream=None, timed: bool = Fals
 
 
 FLAG_CAUSAL = 1  # FA_FLAG_CAUSAL
+
+
+def attention_general_host_half(Q: np.ndarray, K: np.ndarray, V: np.ndarray, causal: bool = False):
+    """``fa_forward_general_host_half``: fp16 NumPy arrays Q [B,H,Lq,D], K/V [B,H,Lk,D] in, (fp16 O,
+    kernel-only ms) out."""
+    B, H, Lq, D = Q.shape
+    Lk = K.shape[2]
+    if K.shape != (B, H, Lk, D) or V.shape != K.shape:
+        raise ValueError("K, V must be [B,H,Lk,D] with Q's B, H, D")
+    O = np.empty_like(Q)
+    ms = ct.c_float(0.0)
+    rc = lib().fa_forward_general_host_half(
+        _np_half_ptr(Q), _np_half_ptr(K), _np_half_ptr(V), _np_half_ptr(O), B, H, Lq, Lk, D,
+        FLAG_CAUSAL if causal else 0, None, ct.byref(ms),
+    )
+    _check(rc)
+    return O, float(ms.value)
 
 
 def attention_general(q, k, v, causal: bool = False, out=None, stream=None, timed: bool = False):

@@ -145,6 +145,41 @@ int timed_launch(hipStream_t stream, float* elapsed_ms, F&& launch_fn) {
     return rc;
 }
 
+// Host-pointer shell shared by the host entry points: four device buffers, Q/K/V host -> device on
+// `stream`, `run(d)` with d = {dQ, dK, dV, dO}, O device -> host, wait, free (wrapper.cu:21-34).
+template <typename F>
+int with_device_copies(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, size_t q_bytes,
+                       size_t kv_bytes, hipStream_t stream, const char* who, F&& run) {
+    const size_t bytes[4] = {q_bytes, kv_bytes, kv_bytes, q_bytes};
+    uint16_t* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = FA_OK;
+    for (int i = 0; i < 4 && rc == FA_OK; ++i)
+        if (hipMalloc(reinterpret_cast<void**>(&d[i]), bytes[i]) != hipSuccess) {
+            std::snprintf(g_last_error, sizeof(g_last_error), "hipMalloc failed in %s", who);
+            rc = FA_ERR_RUNTIME;
+        }
+    auto step = [&](hipError_t e, const char* what) {
+        if (rc == FA_OK && e != hipSuccess) {
+            std::snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s", what, hipGetErrorString(e));
+            rc = FA_ERR_RUNTIME;
+        }
+    };
+    if (rc == FA_OK) {
+        step(hipMemcpyAsync(d[0], hQ, q_bytes, hipMemcpyHostToDevice, stream), "copy Q");
+        step(hipMemcpyAsync(d[1], hK, kv_bytes, hipMemcpyHostToDevice, stream), "copy K");
+        step(hipMemcpyAsync(d[2], hV, kv_bytes, hipMemcpyHostToDevice, stream), "copy V");
+        step(hipStreamSynchronize(stream), "stream sync");
+    }
+    if (rc == FA_OK) rc = run(d);
+    if (rc == FA_OK) {
+        step(hipMemcpyAsync(hO, d[3], q_bytes, hipMemcpyDeviceToHost, stream), "copy O");
+        step(hipStreamSynchronize(stream), "stream sync");
+    }
+    for (int i = 0; i < 4; ++i)
+        if (d[i]) (void)hipFree(d[i]);
+    return rc;
+}
+
 int validate(int B, int H, int L, int D, int tile) {
     if (tile != 64) return fail(FA_ERR_TILE, "run_tensor_flash_attention: tile must be 64%s");
     if (D != fa::kHeadDim) return fail(FA_ERR_HEAD_DIM, "run_tensor_flash_attention: D must be 128%s");
@@ -242,31 +277,25 @@ int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t*
     if (!hQ || !hK || !hV || !hO) return fail(FA_ERR_POINTER, "run_tensor_flash_attention_host_half: null pointer%s");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t bytes = (size_t)B * H * L * D * sizeof(uint16_t);
-    uint16_t* d[4] = {nullptr, nullptr, nullptr, nullptr};
-    int rc = FA_OK;
-    for (int i = 0; i < 4 && rc == FA_OK; ++i)
-        if (hipMalloc(reinterpret_cast<void**>(&d[i]), bytes) != hipSuccess)
-            rc = fail(FA_ERR_RUNTIME, "hipMalloc failed in run_tensor_flash_attention_host_half%s");
-    auto step = [&](hipError_t e, const char* what) {
-        if (rc == FA_OK && e != hipSuccess) {
-            std::snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s", what, hipGetErrorString(e));
-            rc = FA_ERR_RUNTIME;
-        }
-    };
-    if (rc == FA_OK) {
-        step(hipMemcpyAsync(d[0], hQ, bytes, hipMemcpyHostToDevice, stream), "copy Q");
-        step(hipMemcpyAsync(d[1], hK, bytes, hipMemcpyHostToDevice, stream), "copy K");
-        step(hipMemcpyAsync(d[2], hV, bytes, hipMemcpyHostToDevice, stream), "copy V");
-        step(hipStreamSynchronize(stream), "stream sync");
-    }
-    if (rc == FA_OK) rc = fa_forward(d[0], d[1], d[2], d[3], B, H, L, D, tile, stream_, elapsed_ms);
-    if (rc == FA_OK) {
-        step(hipMemcpyAsync(hO, d[3], bytes, hipMemcpyDeviceToHost, stream), "copy O");
-        step(hipStreamSynchronize(stream), "stream sync");
-    }
-    for (int i = 0; i < 4; ++i)
-        if (d[i]) (void)hipFree(d[i]);
-    return rc;
+    return with_device_copies(hQ, hK, hV, hO, bytes, bytes, stream, "run_tensor_flash_attention_host_half",
+                              [&](uint16_t* const* d) -> int {
+                                  return fa_forward(d[0], d[1], d[2], d[3], B, H, L, D, tile, stream_, elapsed_ms);
+                              });
+}
+
+int fa_forward_general_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                                 int H, int Lq, int Lk, int D, int flags, void* stream_, float* elapsed_ms) {
+    g_last_error[0] = 0;
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || D <= 0)
+        return fail(FA_ERR_SHAPE, "fa_forward_general_host_half: sizes must be positive%s");
+    if (!hQ || !hK || !hV || !hO) return fail(FA_ERR_POINTER, "fa_forward_general_host_half: null pointer%s");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t q_bytes = (size_t)B * H * Lq * D * sizeof(uint16_t), kv_bytes = (size_t)B * H * Lk * D * sizeof(uint16_t);
+    return with_device_copies(hQ, hK, hV, hO, q_bytes, kv_bytes, stream, "fa_forward_general_host_half",
+                              [&](uint16_t* const* d) -> int {
+                                  return fa_forward_general(d[0], d[1], d[2], d[3], B, H, Lq, Lk, D, flags, stream_,
+                                                            elapsed_ms);
+                              });
 }
 
 int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
@@ -336,6 +365,28 @@ void run_tensor_flash_attention_host_half(const uint16_t* hQ, const uint16_t* hK
                                           uint16_t* hO, int B, int H, int L, int D, int tile, void* stream,
                                           float* elapsed_ms) {
     if (fa_forward_host_half(hQ, hK, hV, hO, B, H, L, D, tile, stream, elapsed_ms) != FA_OK)
+        throw std::runtime_error(g_last_error);
+}
+
+// The entry points of the reference's two sibling libraries (its naive kernel and its CUDA-core
+// flash kernel), served by the same kernels as everything else, so that a three-way caller such as
+// benchmarks/compare_impls.py:42-63 finds all three symbols.  Host pointers, the reference's error
+// convention.  `causal` is the naive kernel's mask (naive_gpu_attention/normal_attention.cu:50,64,81);
+// the CUDA-core kernel's two launch-shape arguments have no meaning here and are only checked for
+// being positive.
+void run_naive_attention_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                                   int H, int L, int D, int causal, void* stream, float* elapsed_ms) {
+    if (fa_forward_general_host_half(hQ, hK, hV, hO, B, H, L, L, D, causal ? FA_FLAG_CAUSAL : 0, stream,
+                                     elapsed_ms) != FA_OK)
+        throw std::runtime_error(g_last_error);
+}
+
+void run_cuda_cores_flash_attention_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV,
+                                              uint16_t* hO, int B, int H, int L, int D, int KQVO_block_y,
+                                              int number_of_warps_per_block, void* stream, float* elapsed_ms) {
+    if (KQVO_block_y <= 0 || number_of_warps_per_block <= 0)
+        throw std::runtime_error("run_cuda_cores_flash_attention_host_half: launch-shape arguments must be positive");
+    if (fa_forward_general_host_half(hQ, hK, hV, hO, B, H, L, L, D, 0, stream, elapsed_ms) != FA_OK)
         throw std::runtime_error(g_last_error);
 }
 

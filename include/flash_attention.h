@@ -106,6 +106,26 @@ enum { FA_FLAG_CAUSAL = 1 };
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream, float* elapsed_ms);
 
+/* fa_forward_general on host pointers: device buffers allocated per call, copies in and out on
+ * `stream`, waits (the shell of wrapper.cu:21-34). */
+int fa_forward_general_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                                 int H, int Lq, int Lk, int D, int flags, void* stream, float* elapsed_ms);
+
+/* Entry points of the reference's two sibling libraries, so that its three-way caller
+ * (benchmarks/compare_impls.py:17-28,42-63) finds all three symbols in this library (point
+ * libnaive_attention.so and libflash_attention_cuda_cores.so at it).  Same kernels as above; host
+ * pointers; errors thrown as the reference throws them.
+ *   run_naive_attention_host_half             replaces naive_gpu_attention/wrapper.cu:7-39;
+ *                                             `causal` != 0 applies the mask (normal_attention.cu:50,64,81)
+ *   run_cuda_cores_flash_attention_host_half  replaces flash_attention_cuda_cores/wrapper.cu:7-40; its two
+ *                                             launch-shape arguments are checked for being positive and
+ *                                             otherwise ignored */
+void run_naive_attention_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                                   int H, int L, int D, int causal, void* stream, float* elapsed_ms);
+void run_cuda_cores_flash_attention_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV,
+                                              uint16_t* hO, int B, int H, int L, int D, int KQVO_block_y,
+                                              int number_of_warps_per_block, void* stream, float* elapsed_ms);
+
 /* Device-side input generator of the reference's throughput driver
  * (benchmark_tensor_flash_attention.cu:34-41,68-72): element i of the buffer
  * becomes half(fmodf((float)((i*16807+seed)&0xFFFF),1024)/1024-0.5). */

@@ -142,3 +142,31 @@ def test_other_head_dims_rectangular(fa, oracle, dev, D):
     st = oracle.BlockState(1, 3, Lq, D)
     oracle.block_update(st, Q, K, V)
     gate(oracle, oracle.block_finalize(st), O, f"D={D} rectangular")
+
+
+def test_host_pointer_form(fa, oracle):
+    Q, K, V = normal_fp16(31, (1, 2, 100, 128))
+    O, ms = fa.attention_general_host_half(Q, K, V, causal=True)
+    assert ms > 0.0
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, "host pointers, causal, L=100")
+
+
+def test_sibling_library_symbols(fa, oracle):
+    """The reference's three-way caller (benchmarks/compare_impls.py:42-63, 112-141) calls these two with
+    (..., B, H, L, D, 32, 4, None, byref(ms)) and (..., B, H, L, D, 0, None, byref(ms))."""
+    import ctypes as ct
+
+    B, H, L, D = 2, 2, 256, 128
+    Q, K, V = normal_fp16(32, (B, H, L, D))
+    ref = oracle.attention_cpu(Q, K, V)
+    hp = lambda a: a.ctypes.data_as(fa.HalfPtr)
+    for call in ("cuda_cores", "naive", "naive_causal"):
+        O = np.zeros_like(Q)
+        ms = ct.c_float(0.0)
+        if call == "cuda_cores":
+            fa.lib().run_cuda_cores_flash_attention_host_half(hp(Q), hp(K), hp(V), hp(O), B, H, L, D, 32, 4, None, ct.byref(ms))
+        else:
+            fa.lib().run_naive_attention_host_half(hp(Q), hp(K), hp(V), hp(O), B, H, L, D, int(call == "naive_causal"),
+                                                   None, ct.byref(ms))
+        assert ms.value > 0.0
+        gate(oracle, oracle.attention_cpu(Q, K, V, causal=True) if call == "naive_causal" else ref, O, call)
