@@ -6,8 +6,9 @@ Same flow: load the shared library by path with ctypes and the reference's argty
 (:84-87) at B=32,H=16,L=512,D=128, build the fp32 softmax reference with torch when a
 GPU is visible (:94-103), call the host-pointer entry point (:107-110), print MAE / MRE
 (:66-74,129-138) and the kernel-only milliseconds (:140-145).  The reference's two
-optional teaching libraries (CUDA-cores and naive kernels, :17-28) have no counterpart
-here; they are reported as absent exactly as the reference reports a missing file.
+optional sibling libraries (CUDA-cores and naive kernels, :17-28) are single symbols of
+the same library here (served by the same kernels), so the three-way table has three
+rows of one implementation; they are called with the reference's arguments (:112-122).
 """
 import ctypes as ct
 import os
@@ -34,6 +35,15 @@ def load():
         HalfPtr, HalfPtr, HalfPtr, HalfPtr, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, FloatPtr,
     ]
     lib.run_tensor_flash_attention_host_half.restype = None
+    lib.run_cuda_cores_flash_attention_host_half.argtypes = [
+        HalfPtr, HalfPtr, HalfPtr, HalfPtr, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p,
+        FloatPtr,
+    ]
+    lib.run_cuda_cores_flash_attention_host_half.restype = None
+    lib.run_naive_attention_host_half.argtypes = [
+        HalfPtr, HalfPtr, HalfPtr, HalfPtr, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, FloatPtr,
+    ]
+    lib.run_naive_attention_host_half.restype = None
     return lib
 
 
@@ -52,16 +62,14 @@ def metrics(ref32, test16):
     return float(np.mean(ad)), mre
 
 
-def main(B=32, H=16, L=512, D=128, tile=64):
+def main(B=32, H=16, L=512, D=128, tile=64, KQVO_block_y=32, warps=4):
     lib = load()
-    for name in ("flash_attention_cuda_cores", "naive_gpu_attention"):
-        print(f"[warn] {name} shared lib not built in this repository")
     size = B * H * L * D
     rng = np.random.default_rng(0)
     Q = rng.standard_normal(size, dtype=np.float32).astype(np.float16)
     K = rng.standard_normal(size, dtype=np.float32).astype(np.float16)
     V = rng.standard_normal(size, dtype=np.float32).astype(np.float16)
-    O_tc = np.zeros_like(Q)
+    O_tc, O_cc, O_nv = np.zeros_like(Q), np.zeros_like(Q), np.zeros_like(Q)
 
     O_ref = None
     if HAS_TORCH and torch.cuda.is_available():
@@ -76,13 +84,25 @@ def main(B=32, H=16, L=512, D=128, tile=64):
     elapsed = ct.c_float(0.0)
     lib.run_tensor_flash_attention_host_half(
         as_half_ptr(Q), as_half_ptr(K), as_half_ptr(V), as_half_ptr(O_tc), B, H, L, D, tile, None, ct.byref(elapsed))
+    elapsed_cc = ct.c_float(0.0)
+    lib.run_cuda_cores_flash_attention_host_half(
+        as_half_ptr(Q), as_half_ptr(K), as_half_ptr(V), as_half_ptr(O_cc), B, H, L, D, KQVO_block_y, warps, None,
+        ct.byref(elapsed_cc))
+    elapsed_nv = ct.c_float(0.0)
+    lib.run_naive_attention_host_half(
+        as_half_ptr(Q), as_half_ptr(K), as_half_ptr(V), as_half_ptr(O_nv), B, H, L, D, 0, None, ct.byref(elapsed_nv))
 
     ref = O_tc if O_ref is None else O_ref
     print("\nPrecision metrics vs", "Torch ref" if O_ref is not None else "Tensor Cores")
     mae, mre = metrics(ref.astype(np.float32), O_tc)
     print(f"Tensor Cores: MAE={mae:.6f} MRE={mre:.6e}")
+    for name, out in (("CUDA Cores", O_cc), ("Naive", O_nv)):
+        a, r = metrics(ref.astype(np.float32), out)
+        print(f"{name}: MAE={a:.6f} MRE={r:.6e}")
     print("\nSpeed (ms)")
     print(f"Tensor Cores: {elapsed.value:.3f} ms")
+    print(f"CUDA Cores:   {elapsed_cc.value:.3f} ms")
+    print(f"Naive:        {elapsed_nv.value:.3f} ms")
     return mae, mre, elapsed.value
 
 

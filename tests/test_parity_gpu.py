@@ -337,4 +337,8 @@ def test_compare_impls_counterpart():
     mae = float(line.split("MAE=")[1].split()[0])
     mre = float(line.split("MRE=")[1])
     assert mae < 1e-4 and mre < 1.5e-2, line
+    # the sibling libraries' rows (compare_impls.py:133-136) come from the same kernels here
+    for name in ("CUDA Cores", "Naive"):
+        row = [l for l in r.stdout.splitlines() if l.startswith(name + ": MAE=")][0]
+        assert float(row.split("MAE=")[1].split()[0]) < 1e-4, row
     assert "Speed (ms)" in r.stdout
