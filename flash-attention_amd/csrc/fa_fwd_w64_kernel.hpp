@@ -543,7 +543,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     size_t wrow = (size_t)head * p.lq + (size_t)qb * QB + wave * 64;  // this wave's first query row
     Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
 
-    // ---- prologue: K(0..2), V(0..1), the first item's Q rows
+    // ---- prologue: the first item's Q rows, K(0..2), V(0..1).  V(1) and K(2) go last and stay in flight:
+    //      nothing reads them before step 1, and the wait at the end of step 0 covers them.
+    dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
+    dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
     W64_DMA_K(0);
     W64_DMA_V(0);
     W64_ADVANCE(kc);
@@ -553,9 +556,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     W64_DMA_K(2);
     size_t v_next_off = kc.off;  // V(2): what step 0 transfers
     W64_ADVANCE(kc);
-    dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
-    dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
-    wait_all_vmem();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
 
 #ifdef FA_STAMPS  // diagnostic build: shader-clock and 100 MHz counters at entry and exit
