@@ -236,7 +236,7 @@ __device__ __forceinline__ lane_mask_t rescale_needed(float mx, float m_run) {
 template <int BASE>
 __device__ __forceinline__ void rescale_if_needed(lane_mask_t need, float mx, RowState& st) {
     st.m_true = fmaxf(st.m_true, mx);
-    if (need) {
+    if (__builtin_expect(need != 0, 0)) {
         const float m_new = fmaxf(st.m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
         st.m_run = m_new;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         // ---- in the last-but-one step: the next item's Q rows
         int nhead = head, nqb = qb;
         size_t nwrow = wrow;
-        if (more_items && (t + 2 >= n_tiles)) {
+        if (__builtin_expect(more_items && (t + 2 >= n_tiles), 0)) {
             decode_item(p, next_item, nhead, nqb);
             nwrow = (size_t)nhead * p.lq + (size_t)nqb * QB + wave * 64;
             if (t + 2 == n_tiles) {
@@ -669,10 +669,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         // ---- phase 1: matrix side B (S_B(t), O_B += V(t-1).P_B(t-1)), vector side A
         // In an item's last step A's next Q fragments are requested here: Q_A is idle while B is on the
         // matrix side, and the rows arrived with the previous step's end-of-step wait.
-        if (last && more_items) q_install_issue<kQregA>(img, lane);
+        if (__builtin_expect(last && more_items, 0)) q_install_issue<kQregA>(img, lane);
         fused_phase<true, kAccB, kQregB, SC1 * kTileBytes, SC * kTileBytes>(
             w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
-        if (first) {
+        if (__builtin_expect(first, 0)) {
             // O_B of the previous item is complete: write it out, then start the new item's state
             if (b_started) W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
             out_b = wrow;
@@ -684,13 +684,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         // ---- phase 2: matrix side A (S_A(t+1), O_A += V(t).P_A(t)), vector side B
         // In the last step S_A(t+1) belongs to the next item: Q_A must be complete.  B's next fragments are
         // requested now (Q_B is idle in phase 2, whose own wait in gap 16 covers them).
-        if (last && more_items) {
+        if (__builtin_expect(last && more_items, 0)) {
             lds_wait_all();
             q_install_issue<kQregB>(img + 32 * kRowBytes, lane);
         }
         fused_phase<false, kAccA, kQregA, 0, 0>(
             w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
-        if (last) {
+        if (__builtin_expect(last, 0)) {
             W64_WRITE_OUT(kAccA, ra, out_a, img);
             if (!more_items) {
                 // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
 #endif
-        if (last) {
+        if (__builtin_expect(last, 0)) {
             item = next_item;
             head = nhead;
             qb = nqb;
