@@ -55,12 +55,14 @@ int pick_waves(int bh, int lq, int lk) {
 enum KernelId { kKernelW64, kKernelRing, kKernelStaged8, kKernelStaged4 };
 const char* const kKernelNames[] = {"fa::fa_fwd_w64_kernel", "fa::fa_fwd_ring_kernel<8>", "fa::fa_fwd_kernel<8>",
                                     "fa::fa_fwd_kernel<4>"};
-KernelId pick_kernel(int nw, int lk) {
+KernelId pick_kernel(int nw, int lq, int lk) {
     if (nw != 8) return kKernelStaged4;
     bool w64 = true, ring = true;
     if (const char* e = std::getenv("FA_W64")) w64 = std::atoi(e) != 0;
     if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
-    if (w64 && lk >= 3 * fa::kKvTile) return kKernelW64;
+    // (the one-wave-per-SIMD kernel has no notion of a partly filled query block: a forced FA_NWAVES=8
+    // on another row count goes to the ring kernel, which has)
+    if (w64 && lq % 256 == 0 && lk >= 3 * fa::kKvTile) return kKernelW64;
     return ring ? kKernelRing : kKernelStaged8;
 }
 
@@ -98,7 +100,7 @@ int launch(const fa::FwdParams& base, hipStream_t stream) {
     if (const char* e = std::getenv("FA_PERSISTENT"))
         if (std::atoi(e) == 0) grid = items;
     if (grid > items) grid = items;
-    switch (pick_kernel(nw, p.lk)) {
+    switch (pick_kernel(nw, p.lq, p.lk)) {
         case kKernelW64:
             hipLaunchKernelGGL(fa::fa_fwd_w64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
             break;
@@ -206,7 +208,7 @@ extern "C" {
 const char* fa_last_error(void) { return g_last_error; }
 
 const char* fa_version(void) { return "flash_attention gfx950 0.1"; }
-const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(1, lq, lk), lk)]; }
+const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(1, lq, lk), lq, lk)]; }
 
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
                int D, int tile, void* stream_, float* elapsed_ms) {
