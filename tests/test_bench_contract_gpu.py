@@ -1,0 +1,36 @@
+"""GPU tier: bench.py prints ONE JSON line with the fields its callers rely on."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_json_line():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--preheat-seconds", "0.2",
+           "--no-sweep", "--cpu-seconds", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["higher_is_better"] is True
+    assert j["unit"] == "TFLOP/s" and j["value"] > 0 and j["ms_per_step"] > 0
+    assert j["dtype"] == "f16" and j["data"] == "synthetic" and j["scaling"] == "weak"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    # value and ms_per_step describe the same steps: FLOPs of the L=512 README shape
+    assert abs(j["value"] - 4 * 32 * 16 * 512 * 512 * 128 / (j["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * j["value"]
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    assert rf["kernel"] == "fa::fa_fwd_w64_kernel" and rf["kernel_ms"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
