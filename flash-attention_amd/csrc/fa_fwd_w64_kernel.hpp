@@ -275,6 +275,27 @@ __device__ __forceinline__ half8 read_v_at(const W64Geom& w, int kk, int db) {
     return __builtin_bit_cast(half8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// Schedule of the vector slice: how many of Y's 32 score elements have had their exponential started
+// before gap g.  An element costs about 18 issue cycles (fma 4, exp 8, add 4, half a conversion) of the 24
+// an MFMA leaves free, so a gap holds one; W64_SLICE picks where the surplus goes.
+//   0: two per gap in gaps 0-3, one per gap in gaps 4-27 (everything finished inside the phase)
+//   1: one per gap in all 32 gaps (the last sum and the last conversion fall behind the phase);
+//      measured 0.5-2 % faster than 0
+//   2: one per gap in gaps 0-29, a second one in gaps 16 and 17 (the lightest ones); as fast as 1
+#ifndef W64_SLICE
+#define W64_SLICE 1
+#endif
+constexpr int slice_started(int g) {
+    if (g <= 0) return 0;
+#if W64_SLICE == 0
+    return g < 4 ? 2 * g : (g < 28 ? g + 4 : 32);
+#elif W64_SLICE == 1
+    return g < 32 ? g : 32;
+#else
+    return g >= 30 ? 32 : g + (g > 16 ? 1 : 0) + (g > 17 ? 1 : 0);
+#endif
+}
+
 // One phase (see the file comment), written out gap by gap: 32 MFMAs, and after each of them the
 // LDS reads and the slice of vector work that share its 32 cycles; sched_barrier(0) after every gap
 // keeps the compiler from re-ordering across gaps.  X is the sub-block on the matrix side
@@ -348,13 +369,12 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
             }
 #endif
         }
-        // ---- vector slice: Y's 32 scores, two per gap in gaps 0-3 and one per gap in gaps 4-27 (so that
-        //      the whole slice is finished inside the phase); each element is summed one gap after
-        //      its exponential, each pair rounded to fp16 one gap after that
+        // ---- vector slice: Y's 32 scores, spread over the gaps as slice_started() says; each element is
+        //      summed one gap after its exponential, each pair rounded to fp16 one gap after that
         {
-            constexpr int n_done = (gi < 4) ? 2 * gi : ((gi < 28) ? gi + 4 : 32);          // elements started before this gap
-            constexpr int n_new = (gi < 4) ? 2 : ((gi < 28) ? 1 : 0);                        // started in this gap
-            constexpr int n_prev = (gi == 0) ? 0 : ((gi - 1 < 4) ? 2 * (gi - 1) : ((gi - 1 < 28) ? gi + 3 : 32));
+            constexpr int n_done = slice_started(gi);                 // elements started before this gap
+            constexpr int n_new = slice_started(gi + 1) - n_done;     // started in this gap
+            constexpr int n_prev = slice_started(gi - 1);
 #ifndef W64_ABLATE_VEC  // (timing experiments only: wrong results)
             static_for<n_new>([&](auto jc) {
                 constexpr int e = n_done + decltype(jc)::value;
@@ -377,7 +397,7 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
             });
 #endif
             // pairs completed (both summed) before the previous gap's additions: [n_prev2/2, n_prev/2)
-            constexpr int n_prev2 = (gi <= 1) ? 0 : ((gi - 2 < 4) ? 2 * (gi - 2) : ((gi - 2 < 28) ? gi + 2 : 32));
+            constexpr int n_prev2 = slice_started(gi - 2);
             static_for<n_prev / 2 - n_prev2 / 2>([&](auto jc) {
                 constexpr int q = n_prev2 / 2 + decltype(jc)::value;
                 const f32x2 pr = {W64_Y(2 * q), W64_Y(2 * q + 1)};
@@ -404,6 +424,17 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
+    });
+    // what the schedule leaves behind the last gap: sums of the elements started in it, the last conversions
+    static_for<32 - slice_started(31)>([&](auto jc) {
+        constexpr int e = slice_started(31) + decltype(jc)::value;
+        sum += W64_Y(e);
+    });
+    static_for<16 - slice_started(30) / 2>([&](auto jc) {
+        constexpr int q = slice_started(30) / 2 + decltype(jc)::value;
+        const f32x2 pr = {W64_Y(2 * q), W64_Y(2 * q + 1)};
+        const half2_t h = __builtin_convertvector(pr, half2_t);
+        pw[q >> 2][q & 3] = __builtin_bit_cast(unsigned, h);
     });
     l_y += sum;
 #pragma unroll
