@@ -279,6 +279,31 @@ def test_blockwise_entry_point(fa, oracle, torch_dev, nblocks):
         assert np.allclose(st.row_sum.cpu().numpy().reshape(B, H, L), ost.sm, rtol=2e-3)
 
 
+@pytest.mark.parametrize("Lk", [192, 256])
+def test_blockwise_shortest_items_many_per_workgroup(fa, oracle, torch_dev, Lk):
+    """The one-wave-per-SIMD kernel at its minimum of three (and four) K/V tiles per item, with more
+    items than workgroups (300 heads x one 256-row block on 256 CUs): every step is an item's first,
+    last-but-one or last step, and some workgroups carry state across two items."""
+    import torch
+
+    BH, Lq, D, nblk = 300, 256, 128, 2
+    assert fa.lib().fa_kernel_name(Lq, Lk) == b"fa::fa_fwd_w64_kernel"
+    rng = np.random.default_rng(Lk)
+    Q = rng.standard_normal((1, BH, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((1, BH, nblk * Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((1, BH, nblk * Lk, D), dtype=np.float32).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(torch_dev) for a in (Q, K, V)]
+    st = fa.BlockState(BH, Lq, D, torch_dev)
+    out = None
+    for c in range(nblk):
+        out = fa.attention_block(q, k[:, :, c * Lk:(c + 1) * Lk].contiguous(), v[:, :, c * Lk:(c + 1) * Lk].contiguous(),
+                                 st, last=(c == nblk - 1))
+    torch.cuda.synchronize()
+    ost = oracle.BlockState(1, BH, Lq, D)
+    oracle.block_update(ost, Q, K, V)
+    gate(oracle, oracle.block_finalize(ost), out.cpu().numpy(), f"shortest items Lk={Lk}")
+
+
 def test_blockwise_rectangular(fa, oracle, torch_dev):
     """Lq != Lk, blocks visited in rotated (ring) order."""
     import torch
