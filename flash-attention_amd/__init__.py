@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "fa_forward_host_half",
     "fa_forward_block",
     "fa_forward_general",
+    "fa_forward_block_general",
     "fa_forward_general_host_half",
     "run_naive_attention_host_half",
     "run_cuda_cores_flash_attention_host_half",
@@ -76,6 +77,10 @@ def lib() -> ct.CDLL:
         L.fa_forward_block.restype = ct.c_int
         L.fa_forward_general.argtypes = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
         L.fa_forward_general.restype = ct.c_int
+        L.fa_forward_block_general.argtypes = (
+            [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 9 + [ct.c_void_p]
+        )
+        L.fa_forward_block_general.restype = ct.c_int
         L.fa_forward_general_host_half.argtypes = L.fa_forward_general.argtypes
         L.fa_forward_general_host_half.restype = ct.c_int
         # the sibling libraries' symbols, with the argtypes the reference's caller declares
@@ -251,6 +256,37 @@ def attention_block(q, k_blk, v_blk, state: BlockState, last: bool, out=None, st
             _dev_half_ptr(out) if out is not None else None,
             _dev_float_ptr(state.o_acc), _dev_float_ptr(state.row_max), _dev_float_ptr(state.row_sum),
             B * H, Lq, Lk, D, int(state.first), int(last), _stream_handle(stream),
+        )
+    _check(rc)
+    state.first = False
+    return out
+
+
+def attention_block_general(q, k_blk, v_blk, state: BlockState, last: bool, causal: bool = False, q_pos0: int = 0,
+                            k_pos0: int = 0, out=None, stream=None):
+    """One step of the blockwise forward through ``fa_forward_block_general``: any Lq, Lk >= 1, D of
+    64, 128 or 256; with ``causal`` key ``k_pos0 + j`` is visible to query ``q_pos0 + i`` iff it is not
+    ahead of it, so blocks may be folded in any order."""
+    import torch
+
+    B, H, Lq, D = q.shape
+    Lk = k_blk.shape[2]
+    if k_blk.shape != (B, H, Lk, D) or v_blk.shape != k_blk.shape:
+        raise ValueError("k_blk / v_blk must be [B,H,Lk,D]")
+    for t in (q, k_blk, v_blk):
+        if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+            raise ValueError("q, k_blk, v_blk must be contiguous float16 GPU tensors")
+    if last and out is None:
+        out = torch.empty_like(q)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device)
+    with torch.cuda.device(q.device):
+        rc = lib().fa_forward_block_general(
+            _dev_half_ptr(q), _dev_half_ptr(k_blk), _dev_half_ptr(v_blk),
+            _dev_half_ptr(out) if out is not None else None,
+            _dev_float_ptr(state.o_acc), _dev_float_ptr(state.row_max), _dev_float_ptr(state.row_sum),
+            B * H, Lq, Lk, D, FLAG_CAUSAL if causal else 0, int(q_pos0), int(k_pos0), int(state.first), int(last),
+            _stream_handle(stream),
         )
     _check(rc)
     state.first = False

@@ -18,6 +18,13 @@
 //   * with the causal mask a workgroup stops at the tile that holds its last row's diagonal, and a wave
 //     skips the tiles that lie wholly above its own rows (it still helps staging them);
 //   * query rows past the end of Q are computed on a copy of the last row and not stored;
+//   * blockwise mode (kFlagLoadState / kFlagStoreState, as in the tuned kernels): the carried state
+//     (o_acc, row_max, row_sum) is loaded before and stored after the block instead of writing O, and
+//     the causal mask compares absolute positions q_pos0 + i and k_pos0 + j, so that a sequence can be
+//     folded block by block in any order.  Masked scores are -infinity here rather than the CPU
+//     baseline's -1e30: a row that sees no key of a block (or of its first tile) then keeps its state
+//     exactly (with -1e30 and a fresh state the baseline counts exp(0) = 1 for every masked key,
+//     testing.cu:74-77 with :60,:103; it never meets that case because it only runs whole sequences);
 //   * the head dim D is a template parameter: D/16 k-steps per score tile, D/32 output blocks, rows of
 //     2D bytes.  The swizzles keep their form with masks that fit the row: K chunk ^ (row & min(15,
 //     D/8 - 1)), V chunk ^ ((row & min(3, D/32 - 1)) << 2).  D = 256 needs 128 accumulator registers
@@ -30,7 +37,7 @@
 
 namespace fa {
 
-constexpr int kFlagCausal = 4;  // FwdParams::flags: key j > query i is masked (needs lq == lk)
+constexpr int kFlagCausal = 4;  // FwdParams::flags: key k_pos0 + j > query q_pos0 + i is masked
 
 template <int D>
 struct HeadDim {
@@ -133,11 +140,13 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
     const int q_row0 = qb * QB + wave * kRowsPerWave;       // wave-uniform
     const bool wave_valid = q_row0 < p.lq;
     const int q_abs = min(q_row0 + g.r, p.lq - 1);           // this lane's query row (clamped)
-    const int wave_last = min(q_row0 + kRowsPerWave - 1, p.lq - 1);
-    const int key_limit = causal ? min(p.lk - 1, q_abs) : p.lk - 1;  // last key this row may see
+    // key indices are relative to this block of keys; a negative limit means the row sees none of them
+    const int shift = p.q_pos0 - p.k_pos0;
+    const int wave_last = min(q_row0 + kRowsPerWave - 1, p.lq - 1) + shift;  // last key any row of the wave may see
+    const int key_limit = causal ? min(p.lk - 1, q_abs + shift) : p.lk - 1;  // last key this row may see
 
     int n_tiles = (p.lk + kKvTile - 1) / kKvTile;
-    if (causal) n_tiles = min(n_tiles, (min(qb * QB + QB, p.lq) + kKvTile - 1) / kKvTile);
+    if (causal) n_tiles = max(0, min(n_tiles, (min(qb * QB + QB, p.lq) + shift + kKvTile - 1) / kKvTile));
 
     const half_t* kh = p.k + (size_t)head * p.lk * D;
     const half_t* vh = p.v + (size_t)head * p.lk * D;
@@ -173,15 +182,33 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
         for (int ks = 0; ks < HD::kSteps; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qr + ks * 16);
     }
 
+    // running state: m in the log2 domain, l a per-lane partial sum (lanes r and r + 32 are added at the end)
     f32x16 oacc[HD::kBlocks];
     float m_run = -1e30f, m_true = -1e30f, l_run = 0.0f;
+    const size_t srow = (size_t)head * p.lq + q_abs;
+    if (p.flags & kFlagLoadState) {
+        m_run = m_true = p.row_max[srow] * 1.44269504088896340736f;
+        l_run = g.hh == 0 ? p.row_sum[srow] : 0.0f;
+        const float* oa = p.o_acc + srow * D;
 #pragma unroll
-    for (int db = 0; db < HD::kBlocks; ++db)
+        for (int db = 0; db < HD::kBlocks; ++db)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[db][e] = 0.0f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(oa + 32 * db + 8 * g4 + 4 * g.hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[db][4 * g4 + e] = t[e];
+            }
+    } else {
+#pragma unroll
+        for (int db = 0; db < HD::kBlocks; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[db][e] = 0.0f;
+    }
 
-    stage_load(0);
-    stage_write(0);
+    if (n_tiles > 0) {
+        stage_load(0);
+        stage_write(0);
+    }
     __syncthreads();
 
     int buf = 0;
@@ -199,8 +226,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kr = 8 * (e >> 2) + (e & 3);
-                    s0[e] = (kr <= lim) ? s0[e] : -1e30f;
-                    s1[e] = (kr + 32 <= lim) ? s1[e] : -1e30f;
+                    s0[e] = (kr <= lim) ? s0[e] : -__builtin_inff();
+                    s1[e] = (kr + 32 <= lim) ? s1[e] : -__builtin_inff();
                 }
             }
             softmax_tile(s0, s1, p.scale_log2e, m_run, m_true, l_run, oacc, pf);
@@ -211,10 +238,33 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
         buf ^= 1;
     }
 
+    const bool row_valid = wave_valid && q_row0 + g.r < p.lq;
+    if (p.flags & kFlagStoreState) {
+        // hand the state over relative to the true running max, whatever reference was in use
+        const float beta = __builtin_amdgcn_exp2f(m_run - m_true);
+        const float l_tot = half_wave_sum(l_run) * beta;
+        if (row_valid) {
+            if (g.hh == 0) {
+                p.row_max[srow] = m_true * 0.69314718055994530942f;
+                p.row_sum[srow] = l_tot;
+            }
+            float* oa = p.o_acc + srow * D;
+#pragma unroll
+            for (int db = 0; db < HD::kBlocks; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * g4 + e] * beta;
+                    *reinterpret_cast<f32x4*>(oa + 32 * db + 8 * g4 + 4 * g.hh) = t;
+                }
+        }
+        return;
+    }
     // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r
     const float inv = 1.0f / half_wave_sum(l_run);
-    if (wave_valid && q_row0 + g.r < p.lq) {
-        half_t* og = p.o + ((size_t)head * p.lq + q_row0 + g.r) * D;
+    if (row_valid) {
+        half_t* og = p.o + srow * D;
 #pragma unroll
         for (int db = 0; db < HD::kBlocks; ++db)
 #pragma unroll

@@ -65,6 +65,7 @@ struct FwdParams {
     float scale_log2e;  // log2(e)/sqrt(D)
     int flags;
     unsigned long long* stamps;  // diagnostic builds only (FA_STAMPS): 32 time stamps per workgroup
+    int q_pos0, k_pos0;  // absolute position of query row 0 / key row 0 (causal mask of fa_fwd_general_kernel only)
 };
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second.

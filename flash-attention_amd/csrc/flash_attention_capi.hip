@@ -147,6 +147,25 @@ int timed_launch(hipStream_t stream, float* elapsed_ms, F&& launch_fn) {
     return rc;
 }
 
+// The general kernel: one workgroup per (head, 128-row query block), instantiated per head dim.
+int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
+    fa::FwdParams p = base;
+    constexpr int kWaves = 4, kBlockRows = kWaves * fa::kRowsPerWave;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.q_blocks = (p.lq + kBlockRows - 1) / kBlockRows;
+    const long items = (long)p.bh * p.q_blocks;
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "general kernel: grid size out of range%s");
+    const dim3 grid((unsigned)items), block(kWaves * 64);
+    if (D == 64)
+        hipLaunchKernelGGL(fa::fa_fwd_general_kernel<64>, grid, block, 0, stream, p);
+    else if (D == 128)
+        hipLaunchKernelGGL(fa::fa_fwd_general_kernel<128>, grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL(fa::fa_fwd_general_kernel<256>, grid, block, 0, stream, p);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+
 // Host-pointer shell shared by the host entry points: four device buffers, Q/K/V host -> device on
 // `stream`, `run(d)` with d = {dQ, dK, dV, dO}, O device -> host, wait, free (wrapper.cu:21-34).
 template <typename F>
@@ -253,23 +272,41 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     p.bh = B * H;
     p.lq = Lq;
     p.lk = Lk;
-    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
     p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
-    constexpr int kWaves = 4, kBlockRows = kWaves * fa::kRowsPerWave;
-    p.q_blocks = (Lq + kBlockRows - 1) / kBlockRows;
-    const long items = (long)p.bh * p.q_blocks;
-    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "fa_forward_general: grid size out of range%s");
-    return timed_launch(stream, elapsed_ms, [&]() -> int {
-        const dim3 grid((unsigned)items), block(kWaves * 64);
-        if (D == 64)
-            hipLaunchKernelGGL(fa::fa_fwd_general_kernel<64>, grid, block, 0, stream, p);
-        else if (D == 128)
-            hipLaunchKernelGGL(fa::fa_fwd_general_kernel<128>, grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL(fa::fa_fwd_general_kernel<256>, grid, block, 0, stream, p);
-        FA_HIP(hipGetLastError());
-        return FA_OK;
-    });
+    return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
+}
+
+int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
+                             float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int flags, int q_pos0,
+                             int k_pos0, int first, int last, void* stream_) {
+    g_last_error[0] = 0;
+    if (D != 64 && D != 128 && D != 256)
+        return fail(FA_ERR_HEAD_DIM, "fa_forward_block_general: D must be 64, 128 or 256%s");
+    if (Lq <= 0 || Lk <= 0) return fail(FA_ERR_SEQLEN, "fa_forward_block_general: Lq and Lk must be positive%s");
+    if (flags & ~FA_FLAG_CAUSAL) return fail(FA_ERR_SHAPE, "fa_forward_block_general: unknown flag%s");
+    if (q_pos0 < 0 || k_pos0 < 0) return fail(FA_ERR_SHAPE, "fa_forward_block_general: positions must not be negative%s");
+    if (BH <= 0 || BH > 0x7fffffff / 64) return fail(FA_ERR_SHAPE, "fa_forward_block_general: bad BH%s");
+    if (!dQ || !dK || !dV) return fail(FA_ERR_POINTER, "fa_forward_block_general: null tensor pointer%s");
+    if (last && !dO) return fail(FA_ERR_POINTER, "fa_forward_block_general: last step needs dO%s");
+    if ((!first || !last) && (!o_acc || !row_max || !row_sum))
+        return fail(FA_ERR_POINTER, "fa_forward_block_general: state pointers required%s");
+
+    fa::FwdParams p{};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.o_acc = o_acc;
+    p.row_max = row_max;
+    p.row_sum = row_sum;
+    p.bh = BH;
+    p.lq = Lq;
+    p.lk = Lk;
+    p.q_pos0 = q_pos0;
+    p.k_pos0 = k_pos0;
+    p.flags = ((flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0) | (first ? 0 : fa::kFlagLoadState) |
+              (last ? 0 : fa::kFlagStoreState);
+    return launch_general(p, D, static_cast<hipStream_t>(stream_));
 }
 
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,

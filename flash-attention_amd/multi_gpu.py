@@ -16,6 +16,13 @@ nothing here mirrors a reference file; the two modes follow from the math:
   point, and meanwhile passes it to rank r+1 with a send/recv pair.  The merge rule is
   the online-softmax rescale of testing.cu:91-96 applied across blocks.  Non-causal
   attention makes every step the same amount of work on every rank.
+
+* Causal ring (zig-zag).  With the causal mask of attention_cpu (testing.cu:74-77) a
+  contiguous split would leave rank 0 with one block of work and rank P-1 with P.  The
+  sequence is cut into 2P chunks instead and rank r owns chunks r and 2P-1-r: in every
+  ring step each rank then has exactly two (query chunk, key chunk) pairs that are not
+  wholly masked.  Pairs on the diagonal use the mask with absolute positions, pairs below it
+  none, pairs above it are skipped.
 """
 from __future__ import annotations
 
@@ -100,3 +107,91 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
 def ring_block_order(rank: int, world: int):
     """Index of the K/V block rank ``rank`` holds at each step."""
     return [(rank - s) % world for s in range(world)]
+
+
+def zigzag_chunks(rank: int, world: int) -> Tuple[int, int]:
+    """The two chunks (of 2*world) of the sequence that ``rank`` owns in the causal ring."""
+    return rank, 2 * world - 1 - rank
+
+
+def zigzag_schedule(rank: int, world: int):
+    """What rank ``rank`` computes in each of the ``world`` ring steps: a list (per step) of
+    (q_slot, k_slot, q_chunk, k_chunk, diagonal) with q_slot / k_slot in {0, 1} selecting the
+    rank's own and the visiting rank's lower / upper chunk.  Pairs with k_chunk > q_chunk are
+    wholly masked and left out; ``diagonal`` pairs (same chunk) need the mask, the others none."""
+    mine = zigzag_chunks(rank, world)
+    steps = []
+    for s in range(world):
+        theirs = zigzag_chunks((rank - s) % world, world)
+        pairs = []
+        for qs, qc in enumerate(mine):
+            for ks, kc in enumerate(theirs):
+                if kc <= qc:
+                    pairs.append((qs, ks, qc, kc, kc == qc))
+        steps.append(pairs)
+    return steps
+
+
+def run_zigzag_steps(q2, kv_of_step, rank: int, world: int, chunk_len: int, step_fn: Callable, state_factory: Callable):
+    """The compute side of the causal ring for one rank.  q2: [2,B,H,Lc,D] (the rank's lower and
+    upper chunk); ``kv_of_step(s)`` returns the visiting [2(k|v), 2(chunk), B,H,Lc,D] tensor of
+    step s (and may overlap a transfer with the caller's compute).  Returns [2,B,H,Lc,D].
+    ``step_fn(q, k, v, state, last, causal, q_pos0, k_pos0)`` folds one pair."""
+    _, B, H, Lc, D = q2.shape
+    sched = zigzag_schedule(rank, world)
+    states = [state_factory(B * H, Lc, D, q2.device) for _ in range(2)]
+    remaining = [sum(1 for st in sched for pr in st if pr[0] == qs) for qs in range(2)]
+    outs = [None, None]
+    for s in range(world):
+        kv = kv_of_step(s)
+        for qs, ks, qc, kc, diag in sched[s]:
+            remaining[qs] -= 1
+            o = step_fn(q2[qs], kv[0][ks], kv[1][ks], states[qs], remaining[qs] == 0, diag, qc * chunk_len, kc * chunk_len)
+            if remaining[qs] == 0:
+                outs[qs] = o
+    import torch
+
+    return torch.stack(outs)
+
+
+def ring_forward_causal(q2, k2, v2, group=None, step_fn: Optional[Callable] = None,
+                        state_factory: Optional[Callable] = None):
+    """Causal sequence-parallel forward with zig-zag sharding.  q2, k2, v2: [2,B,H,Lc,D], this rank's
+    chunks ``zigzag_chunks(rank, world)`` of a sequence of 2*world*Lc rows.  Returns this rank's rows
+    of O in the same layout.  K and V of both chunks travel as one message per step."""
+    import torch
+    import torch.distributed as dist
+
+    if step_fn is None or state_factory is None:
+        import flash_attention_amd as fa
+
+        def _gpu_step(q, k, v, state, last, causal, q_pos0, k_pos0):
+            return fa.attention_block_general(q, k, v, state, last, causal=causal, q_pos0=q_pos0, k_pos0=k_pos0)
+
+        step_fn = step_fn or _gpu_step
+        state_factory = state_factory or fa.BlockState
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    Lc = q2.shape[3]
+    nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
+    prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
+
+    box = {"cur": torch.stack((k2, v2)).contiguous(), "spare": None, "reqs": []}
+    if world > 1:
+        box["spare"] = torch.empty_like(box["cur"])
+
+    def kv_of_step(s):
+        # finish the transfer that brought this step's block, then start the next one: it
+        # overlaps this step's compute, and `spare` was last read in the step before
+        for r in box["reqs"]:
+            r.wait()
+        if s > 0:
+            box["cur"], box["spare"] = box["spare"], box["cur"]
+        box["reqs"] = []
+        if s + 1 < world:
+            ops = [dist.P2POp(dist.isend, box["cur"], nxt, group), dist.P2POp(dist.irecv, box["spare"], prv, group)]
+            box["reqs"] = dist.batch_isend_irecv(ops)
+        return box["cur"]
+
+    return run_zigzag_steps(q2, kv_of_step, rank, world, Lc, step_fn, state_factory)

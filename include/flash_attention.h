@@ -106,6 +106,16 @@ enum { FA_FLAG_CAUSAL = 1 };
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream, float* elapsed_ms);
 
+/* Blockwise form of fa_forward_general (the state and the first/last convention of fa_forward_block,
+ * any Lq, Lk >= 1, D of 64, 128 or 256).  With FA_FLAG_CAUSAL key j of this block is visible to query
+ * i of this block iff k_pos0 + j <= q_pos0 + i, the positions being those of the rows in the whole
+ * sequence: the blocks of a causal sequence can then be folded in any order (a row that sees no key
+ * of a block keeps its state), which the zig-zag sequence-parallel ring needs.  attention_cpu has
+ * the mask for whole sequences only (testing.cu:74-77). */
+int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
+                             float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int flags, int q_pos0,
+                             int k_pos0, int first, int last, void* stream);
+
 /* fa_forward_general on host pointers: device buffers allocated per call, copies in and out on
  * `stream`, waits (the shell of wrapper.cu:21-34). */
 int fa_forward_general_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,

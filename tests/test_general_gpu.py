@@ -170,3 +170,76 @@ def test_sibling_library_symbols(fa, oracle):
                                                    None, ct.byref(ms))
         assert ms.value > 0.0
         gate(oracle, oracle.attention_cpu(Q, K, V, causal=True) if call == "naive_causal" else ref, O, call)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_blockwise_general_blocks_in_any_order(fa, oracle, dev, D):
+    """fa_forward_block_general: a causal sequence folded from K/V blocks of unequal, ragged sizes in
+    shuffled order, absolute positions given per block; rows that see nothing of a block keep their
+    state.  Reference: attention_cpu with causal=True over the whole sequence."""
+    import torch
+
+    B, H, L = 1, 3, 333
+    Q, K, V = normal_fp16(400 + D, (B, H, L, D))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    cuts = [0, 70, 71, 200, 264, 333]
+    order = [3, 0, 4, 2, 1]  # starts with a block most rows cannot see at all
+    st = fa.BlockState(B * H, L, D, dev)
+    out = None
+    for n, c in enumerate(order):
+        a, b = cuts[c], cuts[c + 1]
+        out = fa.attention_block_general(q, k[:, :, a:b].contiguous(), v[:, :, a:b].contiguous(), st,
+                                         last=(n == len(order) - 1), causal=True, q_pos0=0, k_pos0=a)
+    torch.cuda.synchronize()
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), out.cpu().numpy(), f"any order D={D}")
+
+
+def test_blockwise_general_without_mask_matches_one_pass(fa, oracle, dev):
+    import torch
+
+    B, H, Lq, Lk, D = 2, 2, 100, 500, 128
+    rng = np.random.default_rng(77)
+    Q = rng.standard_normal((B, H, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    st = fa.BlockState(B * H, Lq, D, dev)
+    out = None
+    for n, (a, b) in enumerate([(0, 130), (130, 131), (131, 500)]):
+        out = fa.attention_block_general(q, k[:, :, a:b].contiguous(), v[:, :, a:b].contiguous(), st, last=(n == 2))
+    torch.cuda.synchronize()
+    ost = oracle.BlockState(B, H, Lq, D)
+    oracle.block_update(ost, Q, K, V)
+    gate(oracle, oracle.block_finalize(ost), out.cpu().numpy(), "blockwise general, no mask")
+
+
+def test_causal_zigzag_ring_on_one_gpu(fa, oracle, dev):
+    """The compute schedule of multi_gpu.ring_forward_causal, every rank played in turn on one GPU
+    (the visiting K/V chunks are taken from the full tensors instead of a neighbour)."""
+    import importlib
+
+    import torch
+
+    mg = importlib.import_module("flash_attention_amd.multi_gpu")
+    world, Lc, B, H, D = 4, 96, 1, 2, 128
+    L = 2 * world * Lc
+    Q, K, V = normal_fp16(500, (B, H, L, D))
+    chunk = lambda a, c: torch.from_numpy(np.ascontiguousarray(a[:, :, c * Lc:(c + 1) * Lc])).to(dev)
+
+    def step(q, kk, vv, state, last, causal, q_pos0, k_pos0):
+        return fa.attention_block_general(q, kk, vv, state, last, causal=causal, q_pos0=q_pos0, k_pos0=k_pos0)
+
+    O = np.zeros((B, H, L, D), np.float16)
+    for rank in range(world):
+        lo, hi = mg.zigzag_chunks(rank, world)
+        q2 = torch.stack((chunk(Q, lo), chunk(Q, hi)))
+
+        def kv_of_step(s, rank=rank):
+            a, b = mg.zigzag_chunks((rank - s) % world, world)
+            return torch.stack((torch.stack((chunk(K, a), chunk(K, b))), torch.stack((chunk(V, a), chunk(V, b)))))
+
+        out = mg.run_zigzag_steps(q2, kv_of_step, rank, world, Lc, step, fa.BlockState)
+        torch.cuda.synchronize()
+        O[:, :, lo * Lc:(lo + 1) * Lc] = out[0].cpu().numpy()
+        O[:, :, hi * Lc:(hi + 1) * Lc] = out[1].cpu().numpy()
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, "zig-zag ring on one GPU")

@@ -88,6 +88,63 @@ def _shard_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _make_causal_step(oracle, B, H):
+    def step(q, kb, vb, state, last, causal, q_pos0, k_pos0):
+        Q, K, V = [np.ascontiguousarray(t.numpy()) for t in (q, kb, vb)]
+        if state.inner is None:
+            state.inner = oracle.BlockState(B, H, Q.shape[2], Q.shape[3])
+        oracle.block_update(state.inner, Q, K, V, causal=causal, q_pos0=q_pos0, k_pos0=k_pos0, nthreads=1)
+        return torch.from_numpy(oracle.block_finalize(state.inner)) if last else None
+
+    return step
+
+
+def _causal_ring_worker(rank, world, port, out_dir):
+    mg, oracle = _load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        B, H, Lc, D = 1, 2, 64, 128
+        L = 2 * world * Lc
+        Q, K, V = normal_fp16(102, (B, H, L, D))
+        lo, hi = mg.zigzag_chunks(rank, world)
+        pick = lambda a: torch.from_numpy(np.stack([a[:, :, c * Lc:(c + 1) * Lc] for c in (lo, hi)]))
+        out = mg.ring_forward_causal(pick(Q), pick(K), pick(V), step_fn=_make_causal_step(oracle, B, H),
+                                     state_factory=_CpuState)
+        ref = oracle.attention_cpu(Q, K, V, causal=True, nthreads=1)
+        ref2 = np.stack([ref[:, :, c * Lc:(c + 1) * Lc] for c in (lo, hi)])
+        m = oracle.error_metrics(ref2, out.numpy())
+        ok = m["max_abs"] < 3e-4 and m["global_rel"] < 3e-4
+        open(os.path.join(out_dir, f"cring_{rank}.txt"), "w").write(f"{int(ok)} {m['max_abs']:.3e} {m['global_rel']:.3e}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_causal_zigzag_ring_gloo(tmp_path, world):
+    mp.spawn(_causal_ring_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, *rest = open(tmp_path / f"cring_{r}.txt").read().split()
+        assert ok == "1", (r, rest)
+
+
+def test_zigzag_schedule_properties():
+    """Every (query chunk, key chunk) pair at or below the diagonal is computed exactly once, by the
+    owner of the query chunk, and every rank has the same amount of work in every step."""
+    mg, _ = _load()
+    for world in (1, 2, 3, 8):
+        seen = set()
+        for rank in range(world):
+            for pairs in mg.zigzag_schedule(rank, world):
+                work = sum(0.5 if diag else 1.0 for *_, diag in pairs)
+                assert work == 2.0, (world, rank, pairs)
+                for qs, ks, qc, kc, diag in pairs:
+                    assert qc == mg.zigzag_chunks(rank, world)[qs] and kc <= qc and diag == (kc == qc)
+                    assert (qc, kc) not in seen
+                    seen.add((qc, kc))
+        n = 2 * world
+        assert seen == {(a, b) for a in range(n) for b in range(a + 1)}
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_ring_forward_gloo(tmp_path, world):
     mp.spawn(_ring_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
