@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Soak test of the three kernels that serve 256-row query blocks.
+
+    python tools/fuzz_kernels.py [--iters 300] [--seed 0]
+
+Random shapes (B, H, L = 256k), random input scales, interleaved with launches on other data so that
+registers and LDS hold something else each time.  Every kernel must repeat its own result bit for
+bit; the 8-wave ring kernel (FA_W64=0) and the register-staged kernel (FA_W64=0 FA_RING=0) run the
+same arithmetic in the same order per row and must agree bit for bit with each other; the
+one-wave-per-SIMD kernel adds a row's exponentials in a different order, so it may differ from them
+by the rounding of the result (one fp16 ulp).  Anything else is a scheduling, synchronisation or
+initialisation fault."""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+fa = ge.load_package()
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(args.seed)
+cpu = torch.Generator().manual_seed(args.seed)
+envs = [{}, {"FA_W64": "0"}, {"FA_W64": "0", "FA_RING": "0"}]
+
+def run(q, k, v, env):
+    for a, b in env.items():
+        os.environ[a] = b
+    try:
+        return fa.attention(q, k, v)
+    finally:
+        for a in env:
+            os.environ.pop(a, None)
+
+bad = 0
+noise = [torch.randn((2, 8, 1024, 128), generator=g, device=dev).to(torch.float16) * 30 for _ in range(3)]
+for it in range(args.iters):
+    B = int(torch.randint(1, 5, (1,), generator=cpu))
+    H = int(torch.randint(1, 21, (1,), generator=cpu))
+    L = 256 * int(torch.randint(1, 25, (1,), generator=cpu))
+    scale = float(torch.rand(1, generator=cpu)) * 2.5 + 0.2
+    q, k, v = [(torch.randn((B, H, L, 128), generator=g, device=dev) * scale + 0.3 * (i == 0)).to(torch.float16) for i in range(3)]
+    outs = []
+    for env in envs:
+        run(*noise, {})  # something else passes through the CUs in between
+        outs.append(run(q, k, v, env))
+        outs.append(run(q, k, v, env))
+    torch.cuda.synchronize()
+    a, b = outs[0].float(), outs[2].float()
+    close = bool(((a - b).abs() <= 2.0 ** -9 * torch.maximum(a.abs(), b.abs()) + 1e-6).all())
+    ok = (torch.equal(outs[0], outs[1]) and all(torch.equal(outs[2], o) for o in outs[3:]) and close
+          and bool(torch.isfinite(a).all()))
+    if not ok:
+        bad += 1
+        d = [float((outs[0].float() - o.float()).abs().max()) for o in outs]
+        print(f"iter {it}: B={B} H={H} L={L} scale={scale:.2f}: MISMATCH max|diff| per run {d}")
+    if it % 50 == 49:
+        print(f"{it + 1} shapes, {bad} mismatches", flush=True)
+print("fuzz:", "FAILED" if bad else "ok", f"({args.iters} shapes, {bad} mismatches)")
+sys.exit(1 if bad else 0)
