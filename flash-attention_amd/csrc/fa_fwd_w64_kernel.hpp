@@ -17,9 +17,9 @@
 //
 // Each phase is one basic block of 32 MFMAs with the other sub-block's exponentials, the row-max
 // chain of the scores just produced and the LDS operand reads placed in the gaps between them
-// (sched_group_barrier pins the interleave; an MFMA holds the SIMD's vector issue for only 8 of its
-// 32 cycles).  The rescale decision is the only branch and sits between the blocks, where no MFMA
-// is writing the accumulator.
+// (written out gap by gap with a sched_barrier(0) after each; an MFMA holds the SIMD's vector issue
+// for only 8 of its 32 cycles).  The rescale decision is the only branch and sits between the
+// blocks, where no MFMA is writing the accumulator.
 //
 // K therefore runs one tile ahead of V, and the tile one sub-block multiplies in a phase 2 is the one
 // the other multiplies in the following phase 1.  The K fragments of a tile (64 registers) and its
@@ -35,10 +35,9 @@
 // last-but-one step; the fragment reads into the Q registers are requested one phase before the
 // registers are needed and complete behind that phase (A's during phase 1 of the last step, for
 // phase 2, which already computes S_A of the next item; B's during that phase 2, for phase 1 of the
-// next step).  A sub-block's output is
-// written out (through its half of the image, as whole rows) right after the phase that finished
-// it.  The kernel needs lq % 256 == 0 and at least 3 tiles per item; the launcher sends other
-// shapes to the other kernels.
+// next step).  A sub-block's output is written out (through its half of the image, as whole rows)
+// right after the phase that finished it.  The kernel needs lq % 256 == 0 and at least 3 tiles per
+// item; the launcher sends other shapes to the other kernels.
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -46,13 +45,6 @@
 #include "fa_fwd_ring_kernel.hpp"
 
 namespace fa {
-
-#ifndef W64_K_AHEAD
-#define W64_K_AHEAD 2
-#endif
-#ifndef W64_V_AHEAD
-#define W64_V_AHEAD 4
-#endif
 
 struct RowState {
     float m_run, m_true, l_run;
@@ -266,13 +258,6 @@ __device__ __forceinline__ void launder(W64Geom& r) {
 template <int OFS>
 __device__ __forceinline__ half8 read_k_at(const W64Geom& w, int ks, int blk) {
     return *(lds_half8_ptr)(w.k_ad[ks] + (unsigned)(OFS + blk * 32 * kRowBytes));
-}
-template <int OFS>
-__device__ __forceinline__ half8 read_v_at(const W64Geom& w, int kk, int db) {
-    const unsigned a0 = w.v_ad[db] + (unsigned)(OFS + kk * 16 * kRowBytes);
-    const short4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
-    const short4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 8 * kRowBytes));
-    return __builtin_bit_cast(half8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // Schedule of the vector slice: how many of Y's 32 score elements have had their exponential started
