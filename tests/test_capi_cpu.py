@@ -72,6 +72,32 @@ def test_block_entry_point_validation(fa):
     assert L.fa_init_half(None, 10, 1, None) == 5
 
 
+def test_general_entry_points_validation(fa):
+    """fa_forward_general and its blockwise / host forms refuse bad arguments before any device work."""
+    L = fa.lib()
+    buf = np.zeros(16, dtype=np.float16)
+    f32 = np.zeros(16, dtype=np.float32)
+    h = buf.ctypes.data_as(fa.HalfPtr)
+    f = f32.ctypes.data_as(fa.FloatPtr)
+    gen = lambda B=1, H=1, Lq=10, Lk=10, D=128, flags=0, q=h: L.fa_forward_general(q, h, h, h, B, H, Lq, Lk, D, flags, None, None)
+    assert gen(D=96) == 3 and b"64, 128 or 256" in L.fa_last_error()
+    assert gen(Lq=0) == 2 and gen(Lk=-5) == 2
+    assert gen(flags=2) == 4 and b"unknown flag" in L.fa_last_error()
+    assert gen(Lq=10, Lk=11, flags=1) == 2 and b"causal mask needs Lq == Lk" in L.fa_last_error()
+    assert gen(B=0) == 4 and gen(H=0) == 4
+    assert gen(q=None) == 5
+    blk = lambda Lq=10, Lk=10, D=128, flags=0, qp=0, kp=0, first=1, last=1, o=h, acc=f: L.fa_forward_block_general(
+        h, h, h, o, acc, f, f, 1, Lq, Lk, D, flags, qp, kp, first, last, None)
+    assert blk(D=32) == 3
+    assert blk(Lk=0) == 2
+    assert blk(flags=4) == 4
+    assert blk(qp=-1) == 4 and b"positions" in L.fa_last_error()
+    assert blk(o=None) == 5            # last needs dO
+    assert blk(acc=None, last=0) == 5  # state needed unless first and last
+    assert L.fa_forward_general_host_half(h, h, h, h, 1, 1, 0, 4, 128, 0, None, None) == 4
+    assert L.fa_forward_general_host_half(None, h, h, h, 1, 1, 4, 4, 128, 0, None, None) == 5
+
+
 def test_python_front_end_refuses_cpu_tensors(fa):
     import torch
 
