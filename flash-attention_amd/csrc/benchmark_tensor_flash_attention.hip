@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 
 #include "../../include/flash_attention.h"
@@ -33,8 +34,10 @@
         }                                                                                            \
     } while (0)
 
-int main() {
+int main(int argc, char** argv) {
     const int D = 128, tile = 64, warmup = 3, reps = 5, H = 16;
+    // optional argument: milliseconds of preheat for the steady-state line of each shape (0 = reference figures only)
+    const double steady_ms = argc > 1 ? std::atof(argv[1]) : 1000.0;
     const std::vector<int> seqs = {512, 1024, 2048, 4096, 8192, 16384};
     const std::vector<int> batch = {32, 16, 8, 4, 2, 1};
 
@@ -91,6 +94,31 @@ int main() {
         const double tflops = (flops / (avg_ms / 1000.0)) / 1e12;
         std::printf("B=%d H=%d L=%d: avg_time=%.3f ms, est_TFLOPs=%.3f (%.1f%% of dense fp16 peak)\n", B, H, L, avg_ms,
                     tflops, 100.0 * tflops * 1e12 / peak);
+
+        // The figure above is the reference driver's: one launch per event pair on a chip that idles in
+        // between, so it carries the launch latency and a clock that has not come up.  Steady state:
+        // about a second of back-to-back launches, then `steady_reps` launches between one event pair.
+        if (steady_ms > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < steady_ms) {
+                for (int w = 0; w < 50; ++w) CHECK_FA(fa_forward(dQ, dK, dV, dO, B, H, L, D, tile, nullptr, nullptr));
+                CHECK_HIP(hipDeviceSynchronize());
+            }
+            const int steady_reps = L <= 2048 ? 100 : 20;
+            CHECK_HIP(hipEventCreate(&start));
+            CHECK_HIP(hipEventCreate(&stop));
+            CHECK_HIP(hipEventRecord(start));
+            for (int r = 0; r < steady_reps; ++r) CHECK_FA(fa_forward(dQ, dK, dV, dO, B, H, L, D, tile, nullptr, nullptr));
+            CHECK_HIP(hipEventRecord(stop));
+            CHECK_HIP(hipEventSynchronize(stop));
+            float ms;
+            CHECK_HIP(hipEventElapsedTime(&ms, start, stop));
+            CHECK_HIP(hipEventDestroy(start));
+            CHECK_HIP(hipEventDestroy(stop));
+            const double st = (flops / (ms / steady_reps / 1000.0)) / 1e12;
+            std::printf("    steady state (%d back-to-back launches): %.3f ms, %.3f TFLOP/s (%.1f%%)\n", steady_reps,
+                        ms / steady_reps, st, 100.0 * st * 1e12 / peak);
+        }
     }
     CHECK_HIP(hipFree(dQ));
     CHECK_HIP(hipFree(dK));

@@ -433,7 +433,9 @@ __device__ __forceinline__ void fetch_q_frags(half8 (&qf)[8], const char* img, i
 // counted one (a conditional Q reload inside the loop made the compiler drain all loads, the
 // prefetched tile included, in front of every Q.K^T).
 template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_kernel(const FwdParams p) {
+// (second launch bound: waves per SIMD.  A 4-wave workgroup with its 96 KiB of LDS is alone on its CU,
+// one wave per SIMD, and may use the whole register file; two 4-wave halves of an 8-wave one share a SIMD.)
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void fa_fwd_kernel(const FwdParams p) {
     constexpr int NT = NWAVES * 64;
     constexpr int QB = NWAVES * kRowsPerWave;
     constexpr int CHUNKS = (kTileBytes / 16) / NT;  // 16-byte chunks per thread per tile
