@@ -36,8 +36,9 @@
 // registers are needed and complete behind that phase (A's during phase 1 of the last step, for
 // phase 2, which already computes S_A of the next item; B's during that phase 2, for phase 1 of the
 // next step).  A sub-block's output is written out (through its half of the image, as whole rows)
-// right after the phase that finished it.  The kernel needs lq % 256 == 0 and at least 3 tiles per
-// item; the launcher sends other shapes to the other kernels.
+// right after the phase that finished it.  The kernel needs lq % 64 == 0 (in a last block of fewer than
+// 256 rows some waves have no rows of their own: they compute along on a stand-in and store nothing)
+// and at least 3 tiles per item; the launcher sends other shapes to the other kernels.
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -556,7 +557,17 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     int item = blockIdx.x;
     int head, qb;
     decode_item(p, item, head, qb);
-    size_t wrow = (size_t)head * p.lq + (size_t)qb * QB + wave * 64;  // this wave's first query row
+    // A wave's 64 rows of a query block, or, when the block is the sequence's last and ends before them
+    // (lq is a multiple of 64, not necessarily of 256), the block's first 64 rows as a stand-in source:
+    // such a wave computes along (it moves its share of every tile and meets every barrier) and stores
+    // nothing.  kNoRows marks "no rows to store".
+    constexpr size_t kNoRows = ~(size_t)0;
+    auto source_row = [&](int hd, int blk) -> size_t {
+        const int r0 = blk * QB + wave * 64;
+        return (size_t)hd * p.lq + (size_t)(r0 < p.lq ? r0 : blk * QB);
+    };
+    auto owns_rows = [&](int blk) -> bool { return blk * QB + wave * 64 < p.lq; };
+    size_t wrow = source_row(head, qb);  // this wave's first query row
     Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
 
     // ---- prologue: the first item's Q rows, K(0..2), V(0..1).  V(1) and K(2) go last and stay in flight:
@@ -608,17 +619,21 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     rb.m_run = rb.m_true = -1e30f;
     rb.l_run = 0.0f;
 
-    size_t out_a = wrow, out_b = 0;  // first row of the item whose O_A / O_B is being accumulated
-    bool b_started = false;          // O_B holds an item (false only before the stream's first phase 1)
+    // first row of the item whose O_A / O_B is being accumulated (O_B holds none before the stream's
+    // first phase 1)
+    size_t out_a = owns_rows(qb) ? wrow : kNoRows, out_b = kNoRows;
 
-#define W64_WRITE_OUT(base_, st_, row_, img_)                                                  \
+#define W64_WRITE_OUT(base_, st_, row_, off_, img_)                                            \
     do {                                                                                       \
-        f32x16 o_[4];                                                                          \
-        acc_load<base_>(o_);                                                                   \
-        if (p.flags & kFlagStoreState)                                                         \
-            finish_rows(p, (row_) + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);    \
-        else                                                                                   \
-            store_output_rows(p.o + (row_) * kHeadDim, (img_), lane, o_, (st_).l_run);         \
+        if ((row_) != kNoRows) {                                                               \
+            const size_t r_ = (row_) + (off_);                                                 \
+            f32x16 o_[4];                                                                      \
+            acc_load<base_>(o_);                                                               \
+            if (p.flags & kFlagStoreState)                                                     \
+                finish_rows(p, r_ + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);    \
+            else                                                                               \
+                store_output_rows(p.o + r_ * kHeadDim, (img_), lane, o_, (st_).l_run);         \
+        }                                                                                      \
     } while (0)
     // Start of an item for one sub-block, given the scaled row max mx_ of its first tile.  A fresh item
     // takes that max as its reference at once (nothing to rescale: O = 0, l = 0); a continued one
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         size_t nwrow = wrow;
         if (__builtin_expect(more_items && (t + 2 >= n_tiles), 0)) {
             decode_item(p, next_item, nhead, nqb);
-            nwrow = (size_t)nhead * p.lq + (size_t)nqb * QB + wave * 64;
+            nwrow = source_row(nhead, nqb);
             if (t + 2 == n_tiles) {
                 dma_q_rows_asm(p.q + nwrow * kHeadDim, img, lane);
                 dma_q_rows_asm(p.q + (nwrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
@@ -690,9 +705,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
         if (__builtin_expect(first, 0)) {
             // O_B of the previous item is complete: write it out, then start the new item's state
-            if (b_started) W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
-            out_b = wrow;
-            b_started = true;
+            W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes);
+            out_b = owns_rows(qb) ? wrow : kNoRows;
             W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b);
         }
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
@@ -707,11 +721,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         fused_phase<false, kAccA, kQregA, 0, 0>(
             w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
         if (__builtin_expect(last, 0)) {
-            W64_WRITE_OUT(kAccA, ra, out_a, img);
+            W64_WRITE_OUT(kAccA, ra, out_a, 0, img);
             if (!more_items) {
                 // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
                 pv_only<kAccB>(pb);
-                W64_WRITE_OUT(kAccB, rb, out_b + 32, img + 32 * kRowBytes);
+                W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes);
                 wait_all_vmem();  // the last step's (redundant) transfers must not outlive the workgroup's LDS
 #ifdef FA_STAMPS
                 if (p.stamps && tid == 0) {
@@ -724,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #endif
                 return true;
             }
-            out_a = nwrow;
+            out_a = owns_rows(nqb) ? nwrow : kNoRows;
             W64_INIT(kAccA, ra, nwrow, mx_a, need_a);
         }
         rescale_if_needed<kAccA>(need_a, mx_a, ra);

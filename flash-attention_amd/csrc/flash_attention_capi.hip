@@ -37,32 +37,36 @@ int fail(int code, const char* fmt, const char* detail = "") {
         }                                                                                 \
     } while (0)
 
-// Workgroup size.  8 waves (256 query rows, one workgroup per CU) is the regular shape; 4 waves
-// (128 rows) serve sequence lengths that are not a multiple of 256.
+// Workgroup shape: 256 query rows per workgroup, one workgroup per CU.  A last block of fewer than 256
+// rows leaves some waves without rows of their own (they compute along and store nothing); measured
+// on every L % 64 == 0 from 64 up this still beats 128-row workgroups.  FA_NWAVES=4 selects the 4-wave
+// register-staged kernel for A/B comparisons.
 int pick_waves(int bh, int lq, int lk) {
     (void)bh;
+    (void)lq;
     (void)lk;
     if (const char* e = std::getenv("FA_NWAVES")) {
         const int n = std::atoi(e);
         if (n == 4 || n == 8) return n;
     }
-    return lq % 256 == 0 ? 8 : 4;
+    return 8;
 }
 
-// Which kernel serves a shape.  256-row query blocks go to the one-wave-per-SIMD kernel when an item
-// has at least three K/V tiles (its pipeline depth), otherwise to the 8-wave ring kernel; other row
-// counts to the 4-wave register-staged kernel.  FA_W64=0 / FA_RING=0 step down for A/B comparisons.
+// Which kernel serves a shape.  The one-wave-per-SIMD kernel needs three K/V tiles per item for its
+// pipeline and wins from five on (measured: L = 192 and 256 run 3-8 % faster on the 8-wave ring kernel,
+// L = 320 and up faster here).  FA_W64=1 forces it from three tiles on, FA_W64=0 / FA_RING=0 step down
+// to the older kernels for A/B comparisons.
 enum KernelId { kKernelW64, kKernelRing, kKernelStaged8, kKernelStaged4 };
 const char* const kKernelNames[] = {"fa::fa_fwd_w64_kernel", "fa::fa_fwd_ring_kernel<8>", "fa::fa_fwd_kernel<8>",
                                     "fa::fa_fwd_kernel<4>"};
 KernelId pick_kernel(int nw, int lq, int lk) {
+    (void)lq;
     if (nw != 8) return kKernelStaged4;
-    bool w64 = true, ring = true;
-    if (const char* e = std::getenv("FA_W64")) w64 = std::atoi(e) != 0;
+    int w64_from = 5 * fa::kKvTile;
+    bool ring = true;
+    if (const char* e = std::getenv("FA_W64")) w64_from = std::atoi(e) != 0 ? 3 * fa::kKvTile : 0x7fffffff;
     if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
-    // (the one-wave-per-SIMD kernel has no notion of a partly filled query block: a forced FA_NWAVES=8
-    // on another row count goes to the ring kernel, which has)
-    if (w64 && lq % 256 == 0 && lk >= 3 * fa::kKvTile) return kKernelW64;
+    if (lk >= w64_from) return kKernelW64;
     return ring ? kKernelRing : kKernelStaged8;
 }
 

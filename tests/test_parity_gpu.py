@@ -71,7 +71,7 @@ def test_both_workgroup_sizes(fa, oracle, torch_dev, nwaves, monkeypatch):
 
 
 @pytest.mark.parametrize("env,kernel", [
-    ({}, b"fa::fa_fwd_w64_kernel"),
+    ({"FA_W64": "1"}, b"fa::fa_fwd_w64_kernel"),  # (forced from three tiles on; by default from five)
     ({"FA_W64": "0"}, b"fa::fa_fwd_ring_kernel<8>"),
     ({"FA_W64": "0", "FA_RING": "0"}, b"fa::fa_fwd_kernel<8>"),
 ])
@@ -83,8 +83,9 @@ def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, monkeypatch):
         monkeypatch.setenv(k, v)
     assert fa.lib().fa_kernel_name(512, 512) == kernel
     assert fa.lib().fa_kernel_name(256, 128) != b"fa::fa_fwd_w64_kernel"  # needs three tiles per item
-    assert fa.lib().fa_kernel_name(320, 320) == b"fa::fa_fwd_kernel<4>"
-    for shape in [(1, 1, 256, 128), (2, 3, 768, 128), (1, 9, 1280, 128)]:
+    assert fa.lib().fa_kernel_name(320, 320) == kernel  # a last block of 64 rows: three waves without rows
+    for shape in [(1, 1, 256, 128), (2, 3, 768, 128), (1, 9, 1280, 128), (2, 3, 320, 128), (1, 5, 448, 128),
+                  (1, 3, 960, 128)]:
         Q, K, V = normal_fp16(21, shape)
         O = run_dev(fa, torch_dev, Q, K, V)
         gate(oracle, oracle.attention_cpu(Q, K, V), O, f"{shape} {kernel}")
@@ -107,6 +108,12 @@ def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, monkeypatch):
             K[:, :, 64 * t + (row % 64), :] = (Q[:, :, row, :].astype(np.float32) * (0.15 + 0.08 * t)).astype(np.float16)
     O = run_dev(fa, torch_dev, Q, K, V)
     gate(oracle, oracle.attention_cpu(Q, K, V), O, f"spiked {kernel}")
+
+
+def test_default_kernel_choice(fa):
+    name = fa.lib().fa_kernel_name
+    assert name(512, 512) == name(16384, 16384) == name(320, 320) == name(1984, 1984) == b"fa::fa_fwd_w64_kernel"
+    assert name(64, 64) == name(256, 256) == name(512, 256) == b"fa::fa_fwd_ring_kernel<8>"
 
 
 def test_result_does_not_depend_on_what_ran_before(fa, oracle, torch_dev):
@@ -280,12 +287,13 @@ def test_blockwise_entry_point(fa, oracle, torch_dev, nblocks):
 
 
 @pytest.mark.parametrize("Lk", [192, 256])
-def test_blockwise_shortest_items_many_per_workgroup(fa, oracle, torch_dev, Lk):
+def test_blockwise_shortest_items_many_per_workgroup(fa, oracle, torch_dev, Lk, monkeypatch):
     """The one-wave-per-SIMD kernel at its minimum of three (and four) K/V tiles per item, with more
     items than workgroups (300 heads x one 256-row block on 256 CUs): every step is an item's first,
     last-but-one or last step, and some workgroups carry state across two items."""
     import torch
 
+    monkeypatch.setenv("FA_W64", "1")  # (below five tiles the launcher would pick the ring kernel)
     BH, Lq, D, nblk = 300, 256, 128, 2
     assert fa.lib().fa_kernel_name(Lq, Lk) == b"fa::fa_fwd_w64_kernel"
     rng = np.random.default_rng(Lk)
@@ -302,6 +310,64 @@ def test_blockwise_shortest_items_many_per_workgroup(fa, oracle, torch_dev, Lk):
     ost = oracle.BlockState(1, BH, Lq, D)
     oracle.block_update(ost, Q, K, V)
     gate(oracle, oracle.block_finalize(ost), out.cpu().numpy(), f"shortest items Lk={Lk}")
+
+
+@pytest.mark.parametrize("L", [64, 192, 320, 448, 960])
+def test_partly_filled_last_block_stays_inside_its_tensors(fa, oracle, torch_dev, L):
+    """L % 256 != 0 on 256-row workgroups: inputs are followed by NaNs and the output by a sentinel, so a
+    read past the last head would poison the result and a write past it would show."""
+    import torch
+
+    shape = (2, 3, L, 128)
+    Q, K, V = normal_fp16(30 + L, shape)
+    n = Q.size
+
+    def padded(a, fill):
+        flat = torch.full((n + 65536,), fill, dtype=torch.float16, device=torch_dev)
+        flat[:n] = torch.from_numpy(a).to(torch_dev).reshape(-1)
+        return flat, flat[:n].view(*shape)
+
+    (_, q), (_, k), (_, v) = padded(Q, float("nan")), padded(K, float("nan")), padded(V, float("nan"))
+    o_flat, o = padded(np.zeros(shape, np.float16), 7.0)
+    fa.attention(q, k, v, out=o)
+    torch.cuda.synchronize()
+    assert bool((o_flat[n:] == 7.0).all()), "wrote past the last row"
+    gate(oracle, oracle.attention_cpu(Q, K, V), o.cpu().numpy(), f"L={L}")
+
+
+def test_blockwise_partly_filled_last_query_block(fa, oracle, torch_dev):
+    """Lq = 320: the second 256-row block holds 64 rows, three of its waves have none.  Output, carried
+    accumulator and row statistics sit in buffers with a sentinel tail that must stay untouched."""
+    import torch
+
+    BH, Lq, Lk, D, nblk = 6, 320, 384, 128, 2
+    assert fa.lib().fa_kernel_name(Lq, Lk) == b"fa::fa_fwd_w64_kernel"
+    rng = np.random.default_rng(9)
+    Q = rng.standard_normal((1, BH, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((1, BH, nblk * Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((1, BH, nblk * Lk, D), dtype=np.float32).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(torch_dev) for a in (Q, K, V)]
+
+    def padded(n, dtype, fill):
+        flat = torch.full((n + 8192,), fill, dtype=dtype, device=torch_dev)
+        return flat, flat[:n]
+
+    st = fa.BlockState(BH, Lq, D, torch_dev)
+    acc_flat, acc = padded(BH * Lq * D, torch.float32, 7.0)
+    mx_flat, mx = padded(BH * Lq, torch.float32, 7.0)
+    sm_flat, sm = padded(BH * Lq, torch.float32, 7.0)
+    st.o_acc, st.row_max, st.row_sum = acc.view(BH, Lq, D), mx.view(BH, Lq), sm.view(BH, Lq)
+    o_flat, o = padded(BH * Lq * D, torch.float16, 7.0)
+    out = o.view(1, BH, Lq, D)
+    for c in range(nblk):
+        fa.attention_block(q, k[:, :, c * Lk:(c + 1) * Lk].contiguous(), v[:, :, c * Lk:(c + 1) * Lk].contiguous(), st,
+                           last=(c == nblk - 1), out=out)
+    torch.cuda.synchronize()
+    for flat, n in ((acc_flat, BH * Lq * D), (mx_flat, BH * Lq), (sm_flat, BH * Lq), (o_flat, BH * Lq * D)):
+        assert bool((flat[n:] == 7.0).all()), "wrote past the last row"
+    ost = oracle.BlockState(1, BH, Lq, D)
+    oracle.block_update(ost, Q, K, V)
+    gate(oracle, oracle.block_finalize(ost), out.cpu().numpy(), "partly filled last block, blockwise")
 
 
 def test_blockwise_rectangular(fa, oracle, torch_dev):
