@@ -192,7 +192,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # (FA_BENCH_FORCE_DIST=1 takes the multi-rank code path with a single rank: RCCL init, barrier and
+    # the max-over-ranks reduction can then be exercised on a one-GPU box)
+    if world > 1 or os.environ.get("FA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
@@ -223,6 +225,9 @@ def main():
     o = torch.empty_like(q)
     torch.cuda.synchronize()
 
+    # The first collective sets the communicator up, which takes long enough for the chip to fall back to
+    # its idle clock: it must not sit between the preheat and the timed steps.
+    barrier()
     wall, ms_launch = time_steps(fa, torch, q, k, v, o, args.steps, args.warmup, barrier, args.preheat_seconds)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
