@@ -34,3 +34,23 @@ def test_bench_json_line():
     assert rf["kernel"] == "fa::fa_fwd_w64_kernel" and rf["kernel_ms"] > 0
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_bench_multi_rank_code_path_with_one_rank():
+    """The process-group path of bench.py (RCCL init, barriers, max-over-ranks) on a one-GPU box."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FA_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
+           "--preheat-seconds", "0.3", "--no-sweep", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["scaling"] == "weak"
