@@ -570,20 +570,29 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     size_t wrow = source_row(head, qb);  // this wave's first query row
     Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
 
-    // ---- prologue: the first item's Q rows, K(0..2), V(0..1).  V(1) and K(2) go last and stay in flight:
-    //      nothing reads them before step 1, and the wait at the end of step 0 covers them.
+    // ---- prologue, in three groups so that the first scores start on as little data as possible:
+    //        Q_A rows, K(0)            | waited for first: S_A(0) needs nothing else
+    //        Q_B rows, K(1), V(0)      | waited for before step 0 (behind S_A(0) and the state set-up)
+    //        V(1), K(2)                | stay in flight: nothing reads them before step 1, and the wait at
+    //                                    the end of step 0 covers them
     dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
-    dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
     W64_DMA_K(0);
-    W64_DMA_V(0);
+    dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
+    const size_t off0 = kc.off;
     W64_ADVANCE(kc);
     W64_DMA_K(1);
+    {
+        const size_t off1 = kc.off;
+        kc.off = off0;
+        W64_DMA_V(0);
+        kc.off = off1;
+    }
     W64_DMA_V(1);
     W64_ADVANCE(kc);
     W64_DMA_K(2);
     size_t v_next_off = kc.off;  // V(2): what step 0 transfers
     W64_ADVANCE(kc);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // 8 + 4 + 4 + 8 loads behind the first group
     __syncthreads();
 
 #ifdef FA_STAMPS  // diagnostic build: shader-clock and 100 MHz counters at entry and exit
@@ -591,7 +600,6 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #endif
     acc_reserve();
     q_install<kQregA>(img, lane);
-    q_install<kQregB>(img + 32 * kRowBytes, lane);
 
     f32x16 sa0, sa1, sb0, sb1;
     half8 pa[4], pb[4];
@@ -618,6 +626,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     for (int i = 0; i < 4; ++i) pb[i] = half8{};
     rb.m_run = rb.m_true = -1e30f;
     rb.l_run = 0.0f;
+
+    // the prologue's second group has landed behind the work above
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    q_install<kQregB>(img + 32 * kRowBytes, lane);
 
     // first row of the item whose O_A / O_B is being accumulated (O_B holds none before the stream's
     // first phase 1)
