@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Soak test of fa_forward_general and fa_forward_block_general against the CPU oracle.
 
-    python tools/fuzz_general.py [--iters 200] [--seed 0]
+    python tests/soak/fuzz_general.py [--iters 200] [--seed 0]
 
 Random B, H, Lq, Lk (1..700), D in {64, 128, 256}, with and without the causal mask; every third case
 goes through the blockwise entry point with the keys cut into random blocks folded in random order.
 Gate as in the tests: max-abs <= 2e-3, relative L2 <= 1e-3."""
 import argparse, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge

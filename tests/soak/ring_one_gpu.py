@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The compute side of the sequence-parallel ring, measured on ONE GPU.
 
-    python tools/ring_one_gpu.py [--world 8] [--L 131072] [--rank 3]
+    python tests/soak/ring_one_gpu.py [--world 8] [--L 131072] [--rank 3]
 
 Plays rank `--rank` of a `--world`-way ring over a sequence of `--L` rows (B=1, H=16, D=128; the
 long-sequence configuration of the multi-GPU plan): its L/world query rows are folded against the
@@ -11,7 +11,7 @@ result against the CPU oracle over the full sequence.  (The exchange itself need
 each step moves 2 * 16 * (L/world) * 128 * 2 bytes to the next rank.)"""
 import argparse, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
