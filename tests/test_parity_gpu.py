@@ -409,7 +409,7 @@ def test_error_convention_of_drop_in_symbols():
 
 def test_cpp_correctness_driver():
     """The `testing` binary (counterpart of testing.cu) exits 0 and prints the five metrics."""
-    exe = os.path.join(ROOT, "flash-attention_amd", "csrc", "testing")
+    exe = os.path.join(ROOT, "tests", "cpp", "testing")
     assert os.path.exists(exe), "build it with make -C flash-attention_amd/csrc"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
