@@ -258,7 +258,7 @@ __device__ __forceinline__ void launder(W64Geom& r) {
 }
 template <int OFS>
 __device__ __forceinline__ half8 read_k_at(const W64Geom& w, int ks, int blk) {
-    return *(lds_half8_ptr)(w.k_ad[ks] + (unsigned)(OFS + blk * 32 * kRowBytes));
+    return *(lds_half8_ptr)(size_t)(w.k_ad[ks] + (unsigned)(OFS + blk * 32 * kRowBytes));
 }
 
 // Schedule of the vector slice: how many of Y's 32 score elements have had their exponential started

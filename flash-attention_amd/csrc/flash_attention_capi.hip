@@ -127,9 +127,15 @@ template <typename F>
 int timed_launch(hipStream_t stream, float* elapsed_ms, F&& launch_fn) {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (elapsed_ms) {
-        FA_HIP(hipEventCreate(&ev0));
-        FA_HIP(hipEventCreate(&ev1));
-        FA_HIP(hipEventRecord(ev0, stream));
+        hipError_t e = hipEventCreate(&ev0);
+        if (e == hipSuccess) e = hipEventCreate(&ev1);
+        if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+        if (e != hipSuccess) {
+            std::snprintf(g_last_error, sizeof(g_last_error), "event set-up failed: %s", hipGetErrorString(e));
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+            return FA_ERR_RUNTIME;
+        }
     }
     int rc = launch_fn();
     if (elapsed_ms) {
@@ -215,6 +221,17 @@ int validate(int B, int H, int L, int D, int tile) {
     return FA_OK;
 }
 
+int validate_general(int B, int H, int Lq, int Lk, int D, int flags) {
+    if (D != 64 && D != 128 && D != 256) return fail(FA_ERR_HEAD_DIM, "fa_forward_general: D must be 64, 128 or 256%s");
+    if (Lq <= 0 || Lk <= 0) return fail(FA_ERR_SEQLEN, "fa_forward_general: Lq and Lk must be positive%s");
+    if (flags & ~FA_FLAG_CAUSAL) return fail(FA_ERR_SHAPE, "fa_forward_general: unknown flag%s");
+    if ((flags & FA_FLAG_CAUSAL) && Lq != Lk)
+        return fail(FA_ERR_SEQLEN, "fa_forward_general: the causal mask needs Lq == Lk%s");
+    if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "fa_forward_general: B and H must be positive%s");
+    if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "fa_forward_general: B*H too large%s");
+    return FA_OK;
+}
+
 __global__ void init_half_kernel(fa::half_t* ptr, size_t n, unsigned long long seed) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -256,13 +273,7 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream_, float* elapsed_ms) {
     g_last_error[0] = 0;
-    if (D != 64 && D != 128 && D != 256) return fail(FA_ERR_HEAD_DIM, "fa_forward_general: D must be 64, 128 or 256%s");
-    if (Lq <= 0 || Lk <= 0) return fail(FA_ERR_SEQLEN, "fa_forward_general: Lq and Lk must be positive%s");
-    if (flags & ~FA_FLAG_CAUSAL) return fail(FA_ERR_SHAPE, "fa_forward_general: unknown flag%s");
-    if ((flags & FA_FLAG_CAUSAL) && Lq != Lk)
-        return fail(FA_ERR_SEQLEN, "fa_forward_general: the causal mask needs Lq == Lk%s");
-    if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "fa_forward_general: B and H must be positive%s");
-    if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "fa_forward_general: B*H too large%s");
+    if (int rc = validate_general(B, H, Lq, Lk, D, flags)) return rc;
     if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "fa_forward_general: null tensor pointer%s");
     if (flags == 0 && D == fa::kHeadDim && Lq == Lk && Lq % fa::kKvTile == 0)
         return fa_forward(dQ, dK, dV, dO, B, H, Lq, D, fa::kKvTile, stream_, elapsed_ms);
@@ -329,8 +340,7 @@ int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t*
 int fa_forward_general_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
                                  int H, int Lq, int Lk, int D, int flags, void* stream_, float* elapsed_ms) {
     g_last_error[0] = 0;
-    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || D <= 0)
-        return fail(FA_ERR_SHAPE, "fa_forward_general_host_half: sizes must be positive%s");
+    if (int rc = validate_general(B, H, Lq, Lk, D, flags)) return rc;  // before anything is allocated
     if (!hQ || !hK || !hV || !hO) return fail(FA_ERR_POINTER, "fa_forward_general_host_half: null pointer%s");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t q_bytes = (size_t)B * H * Lq * D * sizeof(uint16_t), kv_bytes = (size_t)B * H * Lk * D * sizeof(uint16_t);

@@ -94,7 +94,7 @@ def test_general_entry_points_validation(fa):
     assert blk(qp=-1) == 4 and b"positions" in L.fa_last_error()
     assert blk(o=None) == 5            # last needs dO
     assert blk(acc=None, last=0) == 5  # state needed unless first and last
-    assert L.fa_forward_general_host_half(h, h, h, h, 1, 1, 0, 4, 128, 0, None, None) == 4
+    assert L.fa_forward_general_host_half(h, h, h, h, 1, 1, 0, 4, 128, 0, None, None) == 2  # as the device form
     assert L.fa_forward_general_host_half(None, h, h, h, 1, 1, 4, 4, 128, 0, None, None) == 5
 
 
