@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "fa_last_error",
     "fa_version",
     "fa_kernel_name",
+    "fa_kernel_name_general",
 )
 
 _lib = None
@@ -99,6 +100,8 @@ def lib() -> ct.CDLL:
         L.fa_version.restype = ct.c_char_p
         L.fa_kernel_name.argtypes = [ct.c_int, ct.c_int]
         L.fa_kernel_name.restype = ct.c_char_p
+        L.fa_kernel_name_general.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int]
+        L.fa_kernel_name_general.restype = ct.c_char_p
         _lib = L
     return _lib
 

@@ -471,7 +471,48 @@ __device__ __forceinline__ void first_scores(W64Geom& w, half8 (&kb0)[8], half8 
     mx_x = half_wave_max(fmaxf(a0, a1)) * c;
 }
 
-__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
+// Causal item order.  With the mask of attention_cpu (testing.cu:74-77: key <= query row) query block qb
+// needs only the tiles up to its diagonal, 4 (qb + 1) of them, so items differ in length.  Items are
+// numbered long ones first (n = 0 is the last query block of head 0), and the workgroups take them in
+// rounds of `grid`, every second round in reverse workgroup order, so that each workgroup's items add up
+// to the same length within one block.  With B*H and the grid multiples of 8 the reversal leaves the low
+// three bits alone: workgroup ids congruent mod 8 share an XCD and keep serving the same heads.
+__device__ __forceinline__ void decode_item_causal(const FwdParams& p, int item, int grid, int& head, int& qb) {
+    const int n_items = p.bh * p.q_blocks;
+    const int k = item / grid, s = item - k * grid;
+    const bool reversed = (k & 1) && (k + 1) * grid <= n_items;  // a partial last round is dealt in plain order
+    int n;
+    if (((p.bh | grid) & 7) == 0) {
+        const int wi = s >> 3;
+        n = k * grid + (reversed ? (grid >> 3) - 1 - wi : wi) * 8 + (s & 7);
+    } else {
+        n = k * grid + (reversed ? grid - 1 - s : s);
+    }
+    const int q = n / p.bh;
+    head = n - q * p.bh;
+    qb = p.q_blocks - 1 - q;
+}
+
+// Causal mask on one sub-block's fresh scores, between two phases.  Register e of key block kb in lane
+// (r, hh) holds key 32 kb + 8 (e >> 2) + (e & 3) + 4 hh of the tile against query row r of the sub-block;
+// thr = (the row's position) - (the tile's first key) - 4 hh, so the element is visible iff
+// 32 kb + 8 (e >> 2) + (e & 3) <= thr.  Masked scores become -inf (their exponential is 0 and they
+// leave the row max alone); mx is recomputed from what stays visible (-inf for a row that sees nothing).
+__device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int thr, float& mx, float c) {
+    const float ninf = -__builtin_inff();
+    float a = ninf;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int kc = 8 * (e >> 2) + (e & 3);
+        s0[e] = kc > thr ? ninf : s0[e];
+        s1[e] = kc + 32 > thr ? ninf : s1[e];
+        a = fmaxf(fmaxf(a, s0[e]), s1[e]);
+    }
+    mx = half_wave_max(a) * c;
+}
+
+template <bool CAUSAL>
+__device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     constexpr int NWAVES = 4;
     constexpr int QB = 256;                        // query rows per item
     constexpr int kImgBytes = 64 * kRowBytes;      // staging image per wave: 64 rows
@@ -508,8 +549,23 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     for (int i = 0; i < 4; ++i) w.v_ad[i] = v_lds + (unsigned)g.v_rd[i];
 
     const int n_items = p.bh * p.q_blocks;
-    const int n_tiles = p.lk / kKvTile;  // >= 3
+    const int n_tiles_all = p.lk / kKvTile;  // >= 3
     const int stride = (int)gridDim.x;
+    // tiles of an item: all of them, or with the mask those up to the query block's diagonal (>= 3 as well)
+    auto item_tiles = [&](int blk) -> int {
+        if constexpr (CAUSAL) {
+            const int n = 4 * (blk + 1);
+            return n < n_tiles_all ? n : n_tiles_all;
+        } else {
+            return n_tiles_all;
+        }
+    };
+    auto decode = [&](int it, int& hd, int& blk) {
+        if constexpr (CAUSAL)
+            decode_item_causal(p, it, stride, hd, blk);
+        else
+            decode_item(p, it, hd, blk);
+    };
     const float c = p.scale_log2e;
     constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
 
@@ -518,19 +574,20 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     //      K transfer of the step before fetched.  Past the end of the stream the cursor stays on the
     //      last tile (redundant transfers into slots nobody reads any more).
     struct Cursor {
-        int item, tile;
+        int item, tile, nt;  // nt: tiles of the cursor's item
         size_t off;
     };
 #define W64_ADVANCE(cur_)                                                                      \
     do {                                                                                       \
-        if (__builtin_expect((cur_).tile + 1 < n_tiles, 1)) {                                  \
+        if (__builtin_expect((cur_).tile + 1 < (CAUSAL ? (cur_).nt : n_tiles_all), 1)) {       \
             ++(cur_).tile;                                                                     \
             (cur_).off += kTileElems;                                                          \
         } else if ((cur_).item + stride < n_items) {                                           \
             (cur_).item += stride;                                                             \
             (cur_).tile = 0;                                                                   \
             int h_, q_;                                                                        \
-            decode_item(p, (cur_).item, h_, q_);                                               \
+            decode((cur_).item, h_, q_);                                                       \
+            (cur_).nt = item_tiles(q_);                                                        \
             (cur_).off = (size_t)h_ * p.lk * kHeadDim;                                         \
         }                                                                                      \
     } while (0)
@@ -556,7 +613,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // ---- compute stream: first item
     int item = blockIdx.x;
     int head, qb;
-    decode_item(p, item, head, qb);
+    decode(item, head, qb);
+    std::conditional_t<CAUSAL, int, const int> n_tiles = item_tiles(qb);  // of the item being computed
     // A wave's 64 rows of a query block, or, when the block is the sequence's last and ends before them
     // (lq is a multiple of 64, not necessarily of 256), the block's first 64 rows as a stand-in source:
     // such a wave computes along (it moves its share of every tile and meets every barrier) and stores
@@ -568,7 +626,14 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     };
     auto owns_rows = [&](int blk) -> bool { return blk * QB + wave * 64 < p.lq; };
     size_t wrow = source_row(head, qb);  // this wave's first query row
-    Cursor kc = {item, 0, (size_t)head * p.lk * kHeadDim};
+    Cursor kc = {item, 0, n_tiles, (size_t)head * p.lk * kHeadDim};
+    // Causal mask: `lim` is the position of the wave's first query row (in keys); a tile whose last key
+    // lies beyond a sub-block's first row takes the mask (mask_scores, between the phases).
+    [[maybe_unused]] int lim = qb * QB + wave * 64;
+    [[maybe_unused]] auto lane_thr = [&]() -> int {
+        const int l_ = opaque(lane);
+        return (l_ & 31) - 4 * (l_ >> 5);
+    };
 
     // ---- prologue, in three groups so that the first scores start on as little data as possible:
     //        Q_A rows, K(0)            | waited for first: S_A(0) needs nothing else
@@ -611,6 +676,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // S_A(0) and its state; P_B = 0 makes the first phase's O_B update a no-op on values that
     // init_state replaces anyway, and S_B needs no value before phase 1 writes it.
     first_scores<kQregA>(w, kb0, kb1, sa0, sa1, mx_a, c);
+    if constexpr (CAUSAL)
+        if (63 > lim) mask_scores(sa0, sa1, lim + lane_thr(), mx_a, c);
     {
         f32x16 o[4];
         init_state(p, wrow + g.r, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
@@ -702,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         int nhead = head, nqb = qb;
         size_t nwrow = wrow;
         if (__builtin_expect(more_items && (t + 2 >= n_tiles), 0)) {
-            decode_item(p, next_item, nhead, nqb);
+            decode(next_item, nhead, nqb);
             nwrow = source_row(nhead, nqb);
             if (t + 2 == n_tiles) {
                 dma_q_rows_asm(p.q + nwrow * kHeadDim, img, lane);
@@ -716,6 +783,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         if (__builtin_expect(last && more_items, 0)) q_install_issue<kQregA>(img, lane);
         fused_phase<true, kAccB, kQregB, SC1 * kTileBytes, SC * kTileBytes>(
             w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
+        if constexpr (CAUSAL) {
+            // S_B(t): rows lim + 32 .. lim + 63 against keys 64 t .. 64 t + 63
+            if (__builtin_expect(64 * t + 31 > lim, 0)) {
+                mask_scores(sb0, sb1, lim + 32 - 64 * t + lane_thr(), mx_b, c);
+                need_b = rescale_needed(mx_b, rb.m_run);
+            }
+        }
         if (__builtin_expect(first, 0)) {
             // O_B of the previous item is complete: write it out, then start the new item's state
             W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes);
@@ -733,6 +807,15 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         }
         fused_phase<false, kAccA, kQregA, 0, 0>(
             w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
+        if constexpr (CAUSAL) {
+            // S_A(t+1), or in an item's last step S_A(0) of the next item: rows lim .. lim + 31
+            const int lim_a = last ? nqb * QB + wave * 64 : lim;
+            const int key0 = last ? 0 : 64 * (t + 1);
+            if (__builtin_expect(key0 + 63 > lim_a, 0)) {
+                mask_scores(sa0, sa1, lim_a - key0 + lane_thr(), mx_a, c);
+                need_a = rescale_needed(mx_a, ra.m_run);
+            }
+        }
         if (__builtin_expect(last, 0)) {
             W64_WRITE_OUT(kAccA, ra, out_a, 0, img);
             if (!more_items) {
@@ -768,6 +851,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             head = nhead;
             qb = nqb;
             wrow = nwrow;
+            if constexpr (CAUSAL) {
+                n_tiles = item_tiles(qb);
+                lim = qb * QB + wave * 64;
+            }
             t = -1;
         }
         ++t;
@@ -779,6 +866,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         if (step(std::integral_constant<int, 2>{})) break;
     }
 }
+
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) { fa_fwd_w64_body<false>(p); }
+// The same with the causal mask (Lq == Lk, positions from 0): per-item tile counts, balanced item order.
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_causal_kernel(const FwdParams p) { fa_fwd_w64_body<true>(p); }
 
 #undef W64_ADVANCE
 #undef W64_DMA_K

@@ -176,6 +176,29 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
     return FA_OK;
 }
 
+// The causal mask on the one-wave-per-SIMD kernel: D = 128, Lq == Lk a multiple of 64 and long enough for
+// its three-tile pipeline.  FA_CAUSAL_W64=0 keeps such shapes on the general kernel (A/B comparisons).
+constexpr int kCausalW64From = 256;
+bool causal_on_w64(int flags, int D, int lq, int lk) {
+    if (!(flags & FA_FLAG_CAUSAL) || D != fa::kHeadDim || lq != lk || lq % fa::kKvTile != 0 || lq < kCausalW64From)
+        return false;
+    if (const char* e = std::getenv("FA_CAUSAL_W64")) return std::atoi(e) != 0;
+    return true;
+}
+int launch_w64_causal(const fa::FwdParams& base, hipStream_t stream) {
+    fa::FwdParams p = base;
+    p.flags = 0;  // whole sequences: no carried state
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
+    p.q_blocks = (p.lq + 255) / 256;
+    const long items = (long)p.bh * p.q_blocks;
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "causal kernel: grid size out of range%s");
+    long grid = (long)device_cus();
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(fa::fa_fwd_w64_causal_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+
 // Host-pointer shell shared by the host entry points: four device buffers, Q/K/V host -> device on
 // `stream`, `run(d)` with d = {dQ, dK, dV, dO}, O device -> host, wait, free (wrapper.cu:21-34).
 template <typename F>
@@ -249,6 +272,11 @@ const char* fa_last_error(void) { return g_last_error; }
 
 const char* fa_version(void) { return "flash_attention gfx950 0.1"; }
 const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(1, lq, lk), lq, lk)]; }
+const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
+    if (flags == 0 && D == fa::kHeadDim && lq == lk && lq > 0 && lq % fa::kKvTile == 0) return fa_kernel_name(lq, lk);
+    if (causal_on_w64(flags, D, lq, lk)) return "fa::fa_fwd_w64_causal_kernel";
+    return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
+}
 
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
                int D, int tile, void* stream_, float* elapsed_ms) {
@@ -288,6 +316,8 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     p.lq = Lq;
     p.lk = Lk;
     p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
+    if (causal_on_w64(flags, D, Lq, Lk))
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_causal(p, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 

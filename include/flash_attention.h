@@ -158,6 +158,8 @@ const char* fa_version(void);
  * counterpart in the reference, whose wrapper picks among seven instantiations of one kernel
  * (flash_attention_tensor_cores/wrapper.cu:89-185). */
 const char* fa_kernel_name(int lq, int lk);
+/* The same for a call of fa_forward_general (flags as there). */
+const char* fa_kernel_name_general(int lq, int lk, int D, int flags);
 
 #ifdef __cplusplus
 }

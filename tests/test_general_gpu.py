@@ -98,6 +98,71 @@ def test_long_causal_row_subset(fa, oracle, dev):
     gate(oracle, ref, O[:, :, rows], "long causal rows")
 
 
+CAUSAL_TUNED = b"fa::fa_fwd_w64_causal_kernel"
+
+
+def test_causal_kernel_choice(fa):
+    """D = 128, Lq == Lk a multiple of 64 from 256 up: the one-wave-per-SIMD kernel with the mask; everything else
+    stays on the general kernel."""
+    name = fa.lib().fa_kernel_name_general
+    for L in (256, 320, 512, 16384):
+        assert name(L, L, 128, 1) == CAUSAL_TUNED
+    assert name(192, 192, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
+    assert name(500, 500, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
+    assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>"
+    assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
+    assert name(512, 100, 128, 0) == b"fa::fa_fwd_general_kernel<128>"
+
+
+@pytest.mark.parametrize("B,H,L", [(1, 3, 256), (2, 3, 320), (1, 5, 448), (2, 4, 512), (1, 3, 576), (1, 2, 1024),
+                                   (1, 3, 1088)])
+def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L):
+    """Whole tensors against attention_cpu(causal); lengths with a partly filled last query block included
+    (320, 448, 576, 1088: waves without rows of their own)."""
+    assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == CAUSAL_TUNED
+    Q, K, V = normal_fp16(300 + L, (B, H, L, 128))
+    O = run_general(fa, dev, Q, K, V, causal=True)
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, f"causal tuned L={L}")
+    assert np.array_equal(O[:, :, 0], V[:, :, 0])  # row 0 sees key 0 only
+
+
+@pytest.mark.parametrize("B,H,L", [(8, 16, 1024), (7, 21, 512), (5, 16, 2560), (3, 5, 1280)])
+def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, monkeypatch):
+    """More items than workgroups: two whole rounds (the second dealt in reverse), a partial second round with
+    B*H not a multiple of 8, two whole rounds plus a partial one, and fewer items than workgroups.  Every row of
+    every head against the general kernel (a head or block computed twice, not at all or with another block's
+    tile count shows there), sampled rows against the oracle."""
+    import torch
+
+    assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == CAUSAL_TUNED
+    Q, K, V = normal_fp16(400 + L, (B, H, L, 128))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = torch.full_like(q, float("nan"))
+    fa.attention_general(q, k, v, causal=True, out=o)
+    monkeypatch.setenv("FA_CAUSAL_W64", "0")
+    assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
+    o_ref = fa.attention_general(q, k, v, causal=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o.float()).all())
+    assert float((o.float() - o_ref.float()).abs().max()) <= 1e-3
+    rows = np.unique(np.concatenate([np.arange(0, L, 61), [255, 256, 257, L - 65, L - 64, L - 1]])).astype(np.int32)
+    ref = oracle.attention_cpu_rows(Q, K, V, rows, causal=True)
+    gate(oracle, ref, o.cpu().numpy()[:, :, rows], f"causal tuned item order {B}x{H}x{L}")
+
+
+def test_causal_tuned_kernel_large_scores(fa, oracle, dev):
+    """Scores of a few hundred with the mask on the tuned kernel: masked entries (often the largest of their
+    tile) must stay out of the row maximum, and the rescale must fire on the visible ones."""
+    rng = np.random.default_rng(11)
+    shape = (1, 4, 512, 128)
+    Q, K = [(rng.standard_normal(shape, dtype=np.float32) * 2.0 + 0.5).astype(np.float16) for _ in range(2)]
+    V = rng.standard_normal(shape, dtype=np.float32).astype(np.float16)
+    # rising scores along the keys: every later (masked) key would dominate the row if it leaked in
+    K = (K.astype(np.float32) * np.linspace(0.5, 1.5, 512, dtype=np.float32)[None, None, :, None]).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V, causal=True)
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, "causal tuned, large scores")
+
+
 def test_tuned_shapes_are_passed_on(fa, dev):
     """Lq == Lk, a multiple of 64, no mask: the same kernel as fa_forward, so the same bits."""
     import torch

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Build-time audit of fa_fwd_w64_kernel, whose inline asm owns the accumulator registers.
+"""Build-time audit of fa_fwd_w64_kernel and fa_fwd_w64_causal_kernel, whose inline asm owns the accumulator registers.
 
 The kernel names a[0:255] literally in its instruction strings; the compiler does not know they hold
 live values.  That is only sound while the compiler itself uses no accumulator register and spills
 nothing in that kernel.  This script compiles the library's device code to assembly and fails if
-the kernel has scratch, spills, or any v_accvgpr_* / a[..] operand outside the #ASMSTART/#ASMEND
+either kernel has scratch, spills, or any v_accvgpr_* / a[..] operand outside the #ASMSTART/#ASMEND
 blocks.
 
     python tools/check_owned_regs.py [extra hipcc flags...]
@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "flash-attention_amd", "csrc", "flash_attention_capi.hip")
-KERNEL = "_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE"
+KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causal_kernelENS_9FwdParamsE"]
 
 
 def main():
@@ -27,6 +27,12 @@ def main():
                "--cuda-device-only", "-o", out, SRC] + sys.argv[1:]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
+    for kernel in KERNELS:
+        audit(text, kernel)
+    print("check_owned_regs: ok (no spills, no scratch, no compiler use of accumulator registers)")
+
+
+def audit(text, KERNEL):
     m = re.search(r"^" + KERNEL + r":.*?\n\s*s_endpgm", text, re.S | re.M)
     if not m:
         sys.exit("check_owned_regs: kernel not found in the assembly")
@@ -55,7 +61,6 @@ def main():
         for p in problems[:20]:
             print("   ", p)
         sys.exit(1)
-    print("check_owned_regs: ok (no spills, no scratch, no compiler use of accumulator registers)")
 
 
 if __name__ == "__main__":
