@@ -176,14 +176,15 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
     return FA_OK;
 }
 
-// The causal mask on the one-wave-per-SIMD kernel: D = 128, Lq == Lk a multiple of 64 and long enough for
-// its three-tile pipeline.  FA_CAUSAL_W64=0 keeps such shapes on the general kernel (A/B comparisons).
-constexpr int kCausalW64From = 256;
+// The causal mask on the one-wave-per-SIMD kernel: D = 128, Lq == Lk a multiple of 64 with at least the three
+// tiles its pipeline needs.  Measured against the general kernel it wins at L = 256 and from 512 up (between
+// those a partly filled last block of idle waves costs more than the general kernel's slower loop).
+// FA_CAUSAL_W64=1 takes it wherever it can run, FA_CAUSAL_W64=0 nowhere (A/B comparisons, tests).
 bool causal_on_w64(int flags, int D, int lq, int lk) {
-    if (!(flags & FA_FLAG_CAUSAL) || D != fa::kHeadDim || lq != lk || lq % fa::kKvTile != 0 || lq < kCausalW64From)
+    if (!(flags & FA_FLAG_CAUSAL) || D != fa::kHeadDim || lq != lk || lq % fa::kKvTile != 0 || lq < 3 * fa::kKvTile)
         return false;
     if (const char* e = std::getenv("FA_CAUSAL_W64")) return std::atoi(e) != 0;
-    return true;
+    return lq >= 512 || lq == 256;
 }
 int launch_w64_causal(const fa::FwdParams& base, hipStream_t stream) {
     fa::FwdParams p = base;

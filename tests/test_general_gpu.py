@@ -101,24 +101,32 @@ def test_long_causal_row_subset(fa, oracle, dev):
 CAUSAL_TUNED = b"fa::fa_fwd_w64_causal_kernel"
 
 
-def test_causal_kernel_choice(fa):
-    """D = 128, Lq == Lk a multiple of 64 from 256 up: the one-wave-per-SIMD kernel with the mask; everything else
-    stays on the general kernel."""
+def test_causal_kernel_choice(fa, monkeypatch):
+    """D = 128, Lq == Lk = 256 or a multiple of 64 from 512 up: the one-wave-per-SIMD kernel with the mask;
+    everything else stays on the general kernel.  FA_CAUSAL_W64=1 extends it to every length it can run."""
     name = fa.lib().fa_kernel_name_general
-    for L in (256, 320, 512, 16384):
+    general = b"fa::fa_fwd_general_kernel<128>"
+    monkeypatch.delenv("FA_CAUSAL_W64", raising=False)
+    for L in (256, 512, 576, 16384):
         assert name(L, L, 128, 1) == CAUSAL_TUNED
-    assert name(192, 192, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
-    assert name(500, 500, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
+    for L in (64, 128, 192, 320, 448, 500):
+        assert name(L, L, 128, 1) == general
     assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>"
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
-    assert name(512, 100, 128, 0) == b"fa::fa_fwd_general_kernel<128>"
+    assert name(512, 100, 128, 0) == general
+    monkeypatch.setenv("FA_CAUSAL_W64", "1")
+    for L in (192, 320, 448):
+        assert name(L, L, 128, 1) == CAUSAL_TUNED
+    assert name(128, 128, 128, 1) == general and name(500, 500, 128, 1) == general
 
 
-@pytest.mark.parametrize("B,H,L", [(1, 3, 256), (2, 3, 320), (1, 5, 448), (2, 4, 512), (1, 3, 576), (1, 2, 1024),
-                                   (1, 3, 1088)])
-def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L):
-    """Whole tensors against attention_cpu(causal); lengths with a partly filled last query block included
-    (320, 448, 576, 1088: waves without rows of their own)."""
+@pytest.mark.parametrize("B,H,L", [(2, 2, 192), (1, 3, 256), (2, 3, 320), (1, 5, 448), (2, 4, 512), (1, 3, 576),
+                                   (1, 2, 1024), (1, 3, 1088)])
+def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L, monkeypatch):
+    """Whole tensors against attention_cpu(causal); the shortest sequence the kernel takes (three tiles) and
+    lengths with a partly filled last query block included (320, 448, 576, 1088: waves without rows of their
+    own)."""
+    monkeypatch.setenv("FA_CAUSAL_W64", "1")
     assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == CAUSAL_TUNED
     Q, K, V = normal_fp16(300 + L, (B, H, L, 128))
     O = run_general(fa, dev, Q, K, V, causal=True)

@@ -5,7 +5,7 @@
 
 Pattern data of the reference's throughput driver, 1 s of preheat, back-to-back launches between two
 events.  FLOPs: 4*B*H*Lq*Lk*D without mask, half of that (the visible triangle, diagonal included:
-2*B*H*L*(L+1)*D) with the causal mask."""
+2*B*H*L*(L+1)*D) with the causal mask.  --causal-sweep: the two causal kernels side by side over L."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,8 @@ buf = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(4)]
 for t, seed in zip(buf[:3], (1234, 2345, 3456)):
     fa.init_half(t, seed)
 
-def run(label, B, L, causal, general=True, reps=20, D=128):
+def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
+    os.environ["FA_CAUSAL_W64"] = "1" if tuned_causal else "0"
     m = B * H * L * D
     q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
     f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))
@@ -41,8 +42,15 @@ def run(label, B, L, causal, general=True, reps=20, D=128):
 for B, L in ((32, 512), (8, 2048), (1, 16384)):
     run("tuned kernel, no mask", B, L, False, general=False)
     run("general kernel, no mask, L-1 (ragged tail)", B, L - 1, False)
-    run("general kernel, causal", B, L, True)
+    run("tuned kernel, causal", B, L, True)
+    run("general kernel, causal", B, L, True, tuned_causal=False)
     run("general kernel, causal, L-1", B, L - 1, True)
+if "--causal-sweep" in sys.argv:
+    for L in (256, 320, 384, 512, 768, 1024, 2048, 4096, 8192, 16384):
+        B = max(1, 16384 // L)
+        run("tuned kernel, causal", B, L, True)
+        run("general kernel, causal", B, L, True, tuned_causal=False)
+    sys.exit(0)
 for D_, shapes in ((64, ((8, 2048), (1, 8192))), (256, ((4, 2048), (1, 8192)))):
     for B, L in shapes:
         run("general kernel, no mask", B, L, False, D=D_)

@@ -9,7 +9,14 @@ bit; the 8-wave ring kernel (FA_W64=0) and the register-staged kernel (FA_W64=0 
 same arithmetic in the same order per row and must agree bit for bit with each other; the
 one-wave-per-SIMD kernel adds a row's exponentials in a different order, so it may differ from them
 by the rounding of the result (one fp16 ulp).  Anything else is a scheduling, synchronisation or
-initialisation fault."""
+initialisation fault.
+
+    python tools/fuzz_kernels.py --causal [--iters 300]
+
+The same for the causal mask: the one-wave-per-SIMD kernel with the mask (FA_CAUSAL_W64=1: wherever it can
+run) against the general kernel (FA_CAUSAL_W64=0), L = 64k from 192 up and B*H up to 400 so that workgroups
+walk several items of different lengths.  Each must repeat itself bit for bit; they may differ from each
+other by the rounding of the result."""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +25,7 @@ import __graft_entry__ as ge
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=300)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--causal", action="store_true")
 args = ap.parse_args()
 fa = ge.load_package()
 dev = torch.device("cuda:0")
@@ -25,10 +33,15 @@ g = torch.Generator(device=dev).manual_seed(args.seed)
 cpu = torch.Generator().manual_seed(args.seed)
 envs = [{"FA_W64": "1"}, {"FA_W64": "0"}, {"FA_W64": "0", "FA_RING": "0"}]  # (FA_W64=1: from three tiles on)
 
+if args.causal:
+    envs = [{"FA_CAUSAL_W64": "1"}, {"FA_CAUSAL_W64": "0"}, {"FA_CAUSAL_W64": "0"}]
+
 def run(q, k, v, env):
     for a, b in env.items():
         os.environ[a] = b
     try:
+        if args.causal and env:
+            return fa.attention_general(q, k, v, causal=True)
         return fa.attention(q, k, v)
     finally:
         for a in env:
@@ -40,6 +53,9 @@ for it in range(args.iters):
     B = int(torch.randint(1, 5, (1,), generator=cpu))
     H = int(torch.randint(1, 21, (1,), generator=cpu))
     L = 64 * int(torch.randint(1, 97, (1,), generator=cpu))  # (a partly filled last 256-row block in 3 of 4 cases)
+    if args.causal:
+        L = 64 * int(torch.randint(3, 49, (1,), generator=cpu))
+        H = int(torch.randint(1, 101, (1,), generator=cpu)) if L <= 1024 else H
     scale = float(torch.rand(1, generator=cpu)) * 2.5 + 0.2
     q, k, v = [(torch.randn((B, H, L, 128), generator=g, device=dev) * scale + 0.3 * (i == 0)).to(torch.float16) for i in range(3)]
     outs = []
