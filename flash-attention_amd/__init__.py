@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "fa_version",
     "fa_kernel_name",
     "fa_kernel_name_general",
+    "fa_kernel_name_block_general",
 )
 
 _lib = None
@@ -102,6 +103,8 @@ def lib() -> ct.CDLL:
         L.fa_kernel_name.restype = ct.c_char_p
         L.fa_kernel_name_general.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int]
         L.fa_kernel_name_general.restype = ct.c_char_p
+        L.fa_kernel_name_block_general.argtypes = [ct.c_int] * 6
+        L.fa_kernel_name_block_general.restype = ct.c_char_p
         _lib = L
     return _lib
 

@@ -188,7 +188,7 @@ bool causal_on_w64(int flags, int D, int lq, int lk) {
 }
 int launch_w64_causal(const fa::FwdParams& base, hipStream_t stream) {
     fa::FwdParams p = base;
-    p.flags = 0;  // whole sequences: no carried state
+    p.flags = base.flags & (fa::kFlagLoadState | fa::kFlagStoreState);
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
     p.q_blocks = (p.lq + 255) / 256;
     const long items = (long)p.bh * p.q_blocks;
@@ -198,6 +198,23 @@ int launch_w64_causal(const fa::FwdParams& base, hipStream_t stream) {
     hipLaunchKernelGGL(fa::fa_fwd_w64_causal_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     FA_HIP(hipGetLastError());
     return FA_OK;
+}
+
+// Which kernel folds one block in fa_forward_block_general.  A block that needs no mask (no flag, or every key of
+// it at or before the first query row) and has the tuned kernels' shape goes to them; the diagonal block of
+// a causal sequence (same positions, same length) to the causal one-wave-per-SIMD kernel where that one is
+// chosen; everything else (ragged sizes, other head dims, blocks the diagonal crosses elsewhere, blocks
+// wholly above it) to the general kernel.  All of them carry the same state.  FA_BLOCK_TUNED=0 keeps
+// everything on the general kernel (A/B comparisons).
+enum BlockRoute { kRouteGeneral, kRouteTuned, kRouteCausalW64 };
+BlockRoute block_route(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
+    if (D != fa::kHeadDim || lq % fa::kKvTile != 0 || lk % fa::kKvTile != 0) return kRouteGeneral;
+    if (const char* e = std::getenv("FA_BLOCK_TUNED"))
+        if (std::atoi(e) == 0) return kRouteGeneral;
+    const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
+    if (!causal || (long)k_pos0 + lk - 1 <= (long)q_pos0) return kRouteTuned;
+    if (q_pos0 == k_pos0 && causal_on_w64(flags, D, lq, lk)) return kRouteCausalW64;
+    return kRouteGeneral;
 }
 
 // Host-pointer shell shared by the host entry points: four device buffers, Q/K/V host -> device on
@@ -273,8 +290,16 @@ const char* fa_last_error(void) { return g_last_error; }
 
 const char* fa_version(void) { return "flash_attention gfx950 0.1"; }
 const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(1, lq, lk), lq, lk)]; }
+const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
+    switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
+        case kRouteTuned: return fa_kernel_name(lq, lk);
+        case kRouteCausalW64: return "fa::fa_fwd_w64_causal_kernel";
+        default: return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
+    }
+}
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
-    if (flags == 0 && D == fa::kHeadDim && lq == lk && lq > 0 && lq % fa::kKvTile == 0) return fa_kernel_name(lq, lk);
+    if (flags == 0 && D == fa::kHeadDim && lq > 0 && lk > 0 && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0)
+        return fa_kernel_name(lq, lk);
     if (causal_on_w64(flags, D, lq, lk)) return "fa::fa_fwd_w64_causal_kernel";
     return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
 }
@@ -317,6 +342,11 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     p.lq = Lq;
     p.lk = Lk;
     p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
+    if (flags == 0 && D == fa::kHeadDim && Lq % fa::kKvTile == 0 && Lk % fa::kKvTile == 0) {
+        // query and key lengths differ, both in whole tiles: the tuned kernels take that as well
+        p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream); });
+    }
     if (causal_on_w64(flags, D, Lq, Lk))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_causal(p, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
@@ -352,7 +382,17 @@ int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint1
     p.k_pos0 = k_pos0;
     p.flags = ((flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0) | (first ? 0 : fa::kFlagLoadState) |
               (last ? 0 : fa::kFlagStoreState);
-    return launch_general(p, D, static_cast<hipStream_t>(stream_));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    switch (block_route(Lq, Lk, D, flags, q_pos0, k_pos0)) {
+        case kRouteTuned:
+            p.flags &= ~fa::kFlagCausal;
+            p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+            return launch(p, stream);
+        case kRouteCausalW64:
+            return launch_w64_causal(p, stream);
+        default:
+            return launch_general(p, D, stream);
+    }
 }
 
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,

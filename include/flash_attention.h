@@ -160,6 +160,8 @@ const char* fa_version(void);
 const char* fa_kernel_name(int lq, int lk);
 /* The same for a call of fa_forward_general (flags as there). */
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags);
+/* The same for a call of fa_forward_block_general. */
+const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0);
 
 #ifdef __cplusplus
 }

@@ -267,6 +267,67 @@ def test_blockwise_general_blocks_in_any_order(fa, oracle, dev, D):
     gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), out.cpu().numpy(), f"any order D={D}")
 
 
+def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, dev, monkeypatch):
+    """fa_forward_block_general sends a block to the tuned kernels when it needs no mask and has their shape, and
+    the diagonal block of a causal sequence to the causal tuned kernel; the kernels carry the same state, so a
+    sequence may mix them: three chunks of 512 rows and a ragged tail of 100, each query chunk folded over its
+    key chunks in shuffled order, against attention_cpu(causal) over the whole sequence."""
+    import torch
+
+    monkeypatch.delenv("FA_CAUSAL_W64", raising=False)
+    monkeypatch.delenv("FA_BLOCK_TUNED", raising=False)
+    name = fa.lib().fa_kernel_name_block_general
+    general, tuned = b"fa::fa_fwd_general_kernel<128>", b"fa::fa_fwd_w64_kernel"
+    assert name(512, 512, 128, 1, 512, 512) == CAUSAL_TUNED     # the diagonal block
+    assert name(512, 512, 128, 1, 1024, 512) == tuned           # wholly below the diagonal: no mask needed
+    assert name(512, 512, 128, 1, 512, 1024) == general         # wholly above it: nothing to see
+    assert name(512, 512, 128, 1, 512, 256) == general          # crossed by the diagonal elsewhere
+    assert name(512, 512, 128, 0, 0, 0) == tuned
+    assert name(512, 100, 128, 0, 0, 0) == general and name(100, 512, 128, 1, 1536, 0) == general
+    assert name(512, 512, 64, 0, 0, 0) == b"fa::fa_fwd_general_kernel<64>"
+
+    B, H, L = 1, 5, 3 * 512 + 100
+    Q, K, V = normal_fp16(77, (B, H, L, 128))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    cuts = [0, 512, 1024, 1536, L]
+    rng = np.random.default_rng(5)
+    out = torch.empty_like(q)
+    for qc in range(4):
+        qa, qe = cuts[qc], cuts[qc + 1]
+        qq = q[:, :, qa:qe].contiguous()
+        st = fa.BlockState(B * H, qe - qa, 128, dev)
+        order = list(rng.permutation(qc + 1))
+        for n, kc in enumerate(order):
+            ka, ke = cuts[kc], cuts[kc + 1]
+            o = fa.attention_block_general(qq, k[:, :, ka:ke].contiguous(), v[:, :, ka:ke].contiguous(), st,
+                                           last=(n == len(order) - 1), causal=True, q_pos0=qa, k_pos0=ka)
+        out[:, :, qa:qe] = o
+    torch.cuda.synchronize()
+    ref = oracle.attention_cpu(Q, K, V, causal=True)
+    gate(oracle, ref, out.cpu().numpy(), "mixed kernels, blockwise causal")
+
+    # the same sequence with everything on the general kernel: same gate (and close to the mixed run)
+    monkeypatch.setenv("FA_BLOCK_TUNED", "0")
+    assert name(512, 512, 128, 1, 512, 512) == general
+    st = fa.BlockState(B * H, L, 128, dev)
+    out_g = fa.attention_block_general(q, k, v, st, last=True, causal=True)
+    torch.cuda.synchronize()
+    gate(oracle, ref, out_g.cpu().numpy(), "general kernel only")
+    assert float((out.float() - out_g.float()).abs().max()) <= 1e-3
+
+
+def test_query_and_key_lengths_in_whole_tiles_go_to_the_tuned_kernels(fa, oracle, dev):
+    assert fa.lib().fa_kernel_name_general(256, 1024, 128, 0) == b"fa::fa_fwd_w64_kernel"
+    rng = np.random.default_rng(21)
+    Q = rng.standard_normal((2, 3, 256, 128), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((2, 3, 1024, 128), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((2, 3, 1024, 128), dtype=np.float32).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V)
+    st = oracle.BlockState(2, 3, 256, 128)
+    oracle.block_update(st, Q, K, V)
+    gate(oracle, oracle.block_finalize(st), O, "Lq=256 Lk=1024 on the tuned kernel")
+
+
 def test_blockwise_general_without_mask_matches_one_pass(fa, oracle, dev):
     import torch
 
