@@ -20,6 +20,7 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   roofline      MFMA roofline of the attention kernel from HIP events over the timed region
   cpu_baseline  the CPU oracle (a port of the reference's attention_cpu) timed on this host
   sweep         the README shapes on this GPU (back-to-back launches between two events)
+  causal_sweep  the same shapes with the causal mask (fa_forward_general), TFLOP/s of the visible triangle
 """
 from __future__ import annotations
 
@@ -56,22 +57,24 @@ def parse_args():
     return ap.parse_args()
 
 
-def preheat(fa, torch, q, k, v, o, seconds):
+def preheat(fa, torch, q, k, v, o, seconds, call=None):
     """The chip raises its clock only under sustained load: measured on L=512, launches that follow
     a few milliseconds of work run at about 1.95 GHz (75 us per launch), launches that follow a second
     of work at about 2.25 GHz (66 us).  Steady-state throughput is what the metric means, so the timed
     region is preceded by this much untimed work, on top of the --warmup steps."""
+    call = call or fa.attention
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(50):
-            fa.attention(q, k, v, out=o)
+            call(q, k, v, out=o)
         torch.cuda.synchronize()
 
 
-def time_steps(fa, torch, q, k, v, o, steps, warmup, barrier, preheat_s=0.0):
-    preheat(fa, torch, q, k, v, o, preheat_s)
+def time_steps(fa, torch, q, k, v, o, steps, warmup, barrier, preheat_s=0.0, call=None):
+    call = call or fa.attention
+    preheat(fa, torch, q, k, v, o, preheat_s, call)
     for _ in range(warmup):
-        fa.attention(q, k, v, out=o)
+        call(q, k, v, out=o)
     torch.cuda.synchronize()
     barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -80,7 +83,7 @@ def time_steps(fa, torch, q, k, v, o, steps, warmup, barrier, preheat_s=0.0):
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
-        fa.attention(q, k, v, out=o)
+        call(q, k, v, out=o)
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -280,6 +283,19 @@ def main():
             tf = 4.0 * Bs * H * Ls * Ls * D / (ms * 1e-3) / 1e12
             sweep.append({"B": Bs, "H": H, "L": Ls, "ms": ms, "tflops": tf, "pct_peak": 100 * tf / PEAK_TFLOPS})
         result["sweep"] = sweep
+        # the same shapes with the causal mask of the reference's CPU baseline (testing.cu:74-77) through
+        # fa_forward_general; FLOPs of the visible triangle, diagonal included
+        causal = []
+        for Bs, Ls in README_SHAPES:
+            n = Bs * H * Ls * D
+            qs, ks, vs, os_ = [t.reshape(-1)[:n].view(Bs, H, Ls, D) for t in (q, k, v, o)]
+            reps = max(5, min(100, int(20.0 * 512 / Ls)))
+            _, ms = time_steps(fa, torch, qs, ks, vs, os_, reps, 3, lambda: None, min(args.preheat_seconds, 0.5),
+                               call=lambda a, b, c, out: fa.attention_general(a, b, c, causal=True, out=out))
+            tf = 2.0 * Bs * H * Ls * (Ls + 1) * D / (ms * 1e-3) / 1e12
+            causal.append({"B": Bs, "H": H, "L": Ls, "ms": ms, "tflops_visible": tf,
+                           "kernel": fa.lib().fa_kernel_name_general(Ls, Ls, D, fa.FLAG_CAUSAL).decode()})
+        result["causal_sweep"] = causal
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(B, H, L, args.cpu_seconds)
