@@ -37,7 +37,6 @@
 
 namespace fa {
 
-constexpr int kFlagCausal = 4;  // FwdParams::flags: key k_pos0 + j > query q_pos0 + i is masked
 
 template <int D>
 struct HeadDim {

@@ -48,6 +48,7 @@ constexpr float kRescaleSlack = 8.0f;            // log2 units a row max may run
 enum : int {
     kFlagLoadState = 1,   // start from (o_acc, row_max, row_sum) instead of zero
     kFlagStoreState = 2,  // write the un-normalised state back instead of fp16 O
+    kFlagCausal = 4,      // key k_pos0 + j > query q_pos0 + i is masked (the kernels that know the mask)
 };
 
 struct FwdParams {
@@ -361,8 +362,9 @@ __device__ __forceinline__ int opaque(int x) {
 // All eight row-wise reads are issued before the first store (the accumulators are dead by then, so
 // registers are plentiful); addresses are one base plus immediates: (4i+row0)&15 = 4(i&3) + row0, so
 // the swizzled chunk of read i is (ch ^ row0) ^ 4(i&3).
+// Rows below first_row (of the 32) are not stored.
 __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
-                                                  float l_run) {
+                                                  float l_run, int first_row = 0) {
     const float inv = 1.0f / half_wave_sum(l_run);
     lane = opaque(lane);
     const int r = lane & 31, hh = lane >> 5;
@@ -393,7 +395,8 @@ __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int
         // streaming store: a plain store leaves the output dirty in the L2 (32 MiB across the chip, half of
         // a 64 MiB output), and the write-back at the end of the kernel then delays the next launch
         // (measured at L=512: 6.7 us between consecutive launches, 4.6 us with these)
-        __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(wr + i * 4 * kHeadDim));
+        if (first_row <= 0 || 4 * i + row0 >= first_row)
+            __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(wr + i * 4 * kHeadDim));
 #endif
     }
 }

@@ -176,26 +176,28 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
     return FA_OK;
 }
 
-// The causal mask on the one-wave-per-SIMD kernel: D = 128, Lq == Lk a multiple of 64 with at least the three
-// tiles its pipeline needs.  Measured against the general kernel it wins at L = 256 and from 512 up (between
-// those a partly filled last block of idle waves costs more than the general kernel's slower loop).
-// FA_CAUSAL_W64=1 takes it wherever it can run, FA_CAUSAL_W64=0 nowhere (A/B comparisons, tests).
-bool causal_on_w64(int flags, int D, int lq, int lk) {
-    if (!(flags & FA_FLAG_CAUSAL) || D != fa::kHeadDim || lq != lk || lq % fa::kKvTile != 0 || lq < 3 * fa::kKvTile)
-        return false;
-    if (const char* e = std::getenv("FA_CAUSAL_W64")) return std::atoi(e) != 0;
-    return lq >= 512 || lq == 256;
+// The masked form of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
+// that are not whole tiles; it needs Lq >= 64 (a wave's rows) and three tiles of keys.  Measured against the
+// general kernel: with the mask it wins at L = 256 and from 512 up (between those a partly filled last block
+// of idle waves costs more than the general kernel's slower loop), without it from five tiles on, as the
+// unmasked kernel against the 8-wave one.  FA_MASKED_W64=1 takes it wherever it can run, FA_MASKED_W64=0
+// nowhere (A/B comparisons, tests).
+bool masked_on_w64(int flags, int D, int lq, int lk) {
+    const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
+    if (D != fa::kHeadDim || lq < 64 || lk < 3 * fa::kKvTile || (causal && lq != lk)) return false;
+    if (!causal && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return false;  // the unmasked kernels' shapes
+    if (const char* e = std::getenv("FA_MASKED_W64")) return std::atoi(e) != 0;
+    return causal ? (lq >= 512 || lq == 256) : lk >= 5 * fa::kKvTile;
 }
-int launch_w64_causal(const fa::FwdParams& base, hipStream_t stream) {
-    fa::FwdParams p = base;
-    p.flags = base.flags & (fa::kFlagLoadState | fa::kFlagStoreState);
+int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
+    fa::FwdParams p = base;  // flags: the state bits and kFlagCausal
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
     p.q_blocks = (p.lq + 255) / 256;
     const long items = (long)p.bh * p.q_blocks;
-    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "causal kernel: grid size out of range%s");
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "masked kernel: grid size out of range%s");
     long grid = (long)device_cus();
     if (grid > items) grid = items;
-    hipLaunchKernelGGL(fa::fa_fwd_w64_causal_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(fa::fa_fwd_w64_masked_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     FA_HIP(hipGetLastError());
     return FA_OK;
 }
@@ -213,7 +215,7 @@ BlockRoute block_route(int lq, int lk, int D, int flags, int q_pos0, int k_pos0)
         if (std::atoi(e) == 0) return kRouteGeneral;
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (!causal || (long)k_pos0 + lk - 1 <= (long)q_pos0) return kRouteTuned;
-    if (q_pos0 == k_pos0 && causal_on_w64(flags, D, lq, lk)) return kRouteCausalW64;
+    if (q_pos0 == k_pos0 && masked_on_w64(flags, D, lq, lk)) return kRouteCausalW64;
     return kRouteGeneral;
 }
 
@@ -293,14 +295,14 @@ const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pic
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
         case kRouteTuned: return fa_kernel_name(lq, lk);
-        case kRouteCausalW64: return "fa::fa_fwd_w64_causal_kernel";
+        case kRouteCausalW64: return "fa::fa_fwd_w64_masked_kernel";
         default: return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
     }
 }
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
     if (flags == 0 && D == fa::kHeadDim && lq > 0 && lk > 0 && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0)
         return fa_kernel_name(lq, lk);
-    if (causal_on_w64(flags, D, lq, lk)) return "fa::fa_fwd_w64_causal_kernel";
+    if (masked_on_w64(flags, D, lq, lk)) return "fa::fa_fwd_w64_masked_kernel";
     return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
 }
 
@@ -347,8 +349,8 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
         p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream); });
     }
-    if (causal_on_w64(flags, D, Lq, Lk))
-        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_causal(p, stream); });
+    if (masked_on_w64(flags, D, Lq, Lk))
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_masked(p, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 
@@ -389,7 +391,7 @@ int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint1
             p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
             return launch(p, stream);
         case kRouteCausalW64:
-            return launch_w64_causal(p, stream);
+            return launch_w64_masked(p, stream);
         default:
             return launch_general(p, D, stream);
     }

@@ -98,26 +98,33 @@ def test_long_causal_row_subset(fa, oracle, dev):
     gate(oracle, ref, O[:, :, rows], "long causal rows")
 
 
-CAUSAL_TUNED = b"fa::fa_fwd_w64_causal_kernel"
+CAUSAL_TUNED = b"fa::fa_fwd_w64_masked_kernel"
 
 
-def test_causal_kernel_choice(fa, monkeypatch):
-    """D = 128, Lq == Lk = 256 or a multiple of 64 from 512 up: the one-wave-per-SIMD kernel with the mask;
-    everything else stays on the general kernel.  FA_CAUSAL_W64=1 extends it to every length it can run."""
+def test_masked_kernel_choice(fa, monkeypatch):
+    """D = 128 with the causal mask (Lq == Lk = 256 or from 512 up) or ragged lengths (Lq >= 64, Lk from five
+    tiles up): the masked form of the one-wave-per-SIMD kernel; everything else stays on the general kernel.
+    FA_MASKED_W64=1 extends it to every shape it can run (Lq >= 64, three tiles of keys)."""
     name = fa.lib().fa_kernel_name_general
     general = b"fa::fa_fwd_general_kernel<128>"
-    monkeypatch.delenv("FA_CAUSAL_W64", raising=False)
-    for L in (256, 512, 576, 16384):
+    monkeypatch.delenv("FA_MASKED_W64", raising=False)
+    for L in (256, 512, 576, 700, 16383, 16384):
         assert name(L, L, 128, 1) == CAUSAL_TUNED
     for L in (64, 128, 192, 320, 448, 500):
         assert name(L, L, 128, 1) == general
-    assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>"
+    for Lq, Lk in ((511, 511), (64, 321), (100, 4000), (2047, 2047), (300, 320)):
+        assert name(Lq, Lk, 128, 0) == CAUSAL_TUNED
+    for Lq, Lk in ((63, 1000), (511, 300), (1, 5000), (200, 319)):
+        assert name(Lq, Lk, 128, 0) == general
+    assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>" and name(511, 511, 256, 0).endswith(b"<256>")
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
-    assert name(512, 100, 128, 0) == general
-    monkeypatch.setenv("FA_CAUSAL_W64", "1")
-    for L in (192, 320, 448):
+    monkeypatch.setenv("FA_MASKED_W64", "1")
+    for L in (192, 320, 448, 200, 500):
         assert name(L, L, 128, 1) == CAUSAL_TUNED
-    assert name(128, 128, 128, 1) == general and name(500, 500, 128, 1) == general
+    assert name(64, 193, 128, 0) == CAUSAL_TUNED
+    assert name(128, 128, 128, 1) == general and name(63, 500, 128, 0) == general and name(100, 191, 128, 0) == general
+    monkeypatch.setenv("FA_MASKED_W64", "0")
+    assert name(512, 512, 128, 1) == general and name(511, 511, 128, 0) == general
 
 
 @pytest.mark.parametrize("B,H,L", [(2, 2, 192), (1, 3, 256), (2, 3, 320), (1, 5, 448), (2, 4, 512), (1, 3, 576),
@@ -126,7 +133,7 @@ def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L, monkeypatch):
     """Whole tensors against attention_cpu(causal); the shortest sequence the kernel takes (three tiles) and
     lengths with a partly filled last query block included (320, 448, 576, 1088: waves without rows of their
     own)."""
-    monkeypatch.setenv("FA_CAUSAL_W64", "1")
+    monkeypatch.setenv("FA_MASKED_W64", "1")
     assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == CAUSAL_TUNED
     Q, K, V = normal_fp16(300 + L, (B, H, L, 128))
     O = run_general(fa, dev, Q, K, V, causal=True)
@@ -147,7 +154,7 @@ def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, monkeypatch):
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
     o = torch.full_like(q, float("nan"))
     fa.attention_general(q, k, v, causal=True, out=o)
-    monkeypatch.setenv("FA_CAUSAL_W64", "0")
+    monkeypatch.setenv("FA_MASKED_W64", "0")
     assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
     o_ref = fa.attention_general(q, k, v, causal=True)
     torch.cuda.synchronize()
@@ -156,6 +163,58 @@ def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, monkeypatch):
     rows = np.unique(np.concatenate([np.arange(0, L, 61), [255, 256, 257, L - 65, L - 64, L - 1]])).astype(np.int32)
     ref = oracle.attention_cpu_rows(Q, K, V, rows, causal=True)
     gate(oracle, ref, o.cpu().numpy()[:, :, rows], f"causal tuned item order {B}x{H}x{L}")
+
+
+@pytest.mark.parametrize("Lq,Lk,causal", [(64, 193, False), (65, 200, False), (100, 321, False), (511, 511, False),
+                                          (513, 513, False), (300, 1000, False), (777, 640, False), (640, 777, False),
+                                          (255, 255, True), (257, 257, True), (200, 200, True), (511, 511, True),
+                                          (513, 513, True), (1000, 1000, True), (1087, 1087, True)])
+def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, monkeypatch):
+    """Lengths that are not whole tiles on the masked kernel: the last key tile is read shifted down to the last
+    key (its repeated rows masked), a wave whose rows would pass the last query row takes the last 64 rows and
+    stores only its own.  NaN-padded inputs and a sentinel-padded output catch reads and writes past the end."""
+    monkeypatch.setenv("FA_MASKED_W64", "1")
+    assert fa.lib().fa_kernel_name_general(Lq, Lk, 128, int(causal)) == CAUSAL_TUNED
+    rng = np.random.default_rng(Lq * 7 + Lk)
+    B, H = 2, 3
+    Q = rng.standard_normal((B, H, Lq, 128), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((B, H, Lk, 128), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((B, H, Lk, 128), dtype=np.float32).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V, causal=causal)
+    if causal:
+        ref = oracle.attention_cpu(Q, K, V, causal=True)
+    else:
+        st = oracle.BlockState(B, H, Lq, 128)
+        oracle.block_update(st, Q, K, V)
+        ref = oracle.block_finalize(st)
+    gate(oracle, ref, O, f"ragged tuned Lq={Lq} Lk={Lk} causal={causal}")
+    O2 = run_general(fa, dev, Q, K, V, causal=causal)
+    assert np.array_equal(O, O2)  # rows computed by two waves are stored by one: repeats are bit-exact
+
+
+@pytest.mark.parametrize("B,H,L,causal", [(9, 16, 1000, False), (7, 21, 575, True), (4, 16, 2100, True)])
+def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, monkeypatch):
+    """Several items per workgroup with ragged lengths: every row against the general kernel, sampled rows
+    against the oracle."""
+    import torch
+
+    monkeypatch.delenv("FA_MASKED_W64", raising=False)
+    assert fa.lib().fa_kernel_name_general(L, L, 128, int(causal)) == CAUSAL_TUNED
+    Q, K, V = normal_fp16(500 + L, (B, H, L, 128))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = torch.full_like(q, float("nan"))
+    fa.attention_general(q, k, v, causal=causal, out=o)
+    monkeypatch.setenv("FA_MASKED_W64", "0")
+    o_ref = fa.attention_general(q, k, v, causal=causal)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o.float()).all())
+    assert float((o.float() - o_ref.float()).abs().max()) <= 1e-3
+    rows = np.unique(np.concatenate([np.arange(0, L, 61), [255, 256, 257, L - 65, L - 64, L - 2, L - 1]])).astype(np.int32)
+    if causal:
+        ref = oracle.attention_cpu_rows(Q, K, V, rows, causal=True)
+    else:
+        ref = oracle.attention_cpu_rows(Q, K, V, rows)
+    gate(oracle, ref, o.cpu().numpy()[:, :, rows], f"ragged tuned, many items {B}x{H}x{L} causal={causal}")
 
 
 def test_causal_tuned_kernel_large_scores(fa, oracle, dev):
@@ -274,7 +333,7 @@ def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, d
     key chunks in shuffled order, against attention_cpu(causal) over the whole sequence."""
     import torch
 
-    monkeypatch.delenv("FA_CAUSAL_W64", raising=False)
+    monkeypatch.delenv("FA_MASKED_W64", raising=False)
     monkeypatch.delenv("FA_BLOCK_TUNED", raising=False)
     name = fa.lib().fa_kernel_name_block_general
     general, tuned = b"fa::fa_fwd_general_kernel<128>", b"fa::fa_fwd_w64_kernel"

@@ -20,7 +20,7 @@ for t, seed in zip(buf[:3], (1234, 2345, 3456)):
     fa.init_half(t, seed)
 
 def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
-    os.environ["FA_CAUSAL_W64"] = "1" if tuned_causal else "0"
+    os.environ["FA_MASKED_W64"] = "1" if tuned_causal else "0"
     m = B * H * L * D
     q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
     f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time audit of fa_fwd_w64_kernel and fa_fwd_w64_causal_kernel, whose inline asm owns the accumulator registers.
+"""Build-time audit of fa_fwd_w64_kernel and fa_fwd_w64_masked_kernel, whose inline asm owns the accumulator registers.
 
 The kernel names a[0:255] literally in its instruction strings; the compiler does not know they hold
 live values.  That is only sound while the compiler itself uses no accumulator register and spills
@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "flash-attention_amd", "csrc", "flash_attention_capi.hip")
-KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causal_kernelENS_9FwdParamsE"]
+KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_masked_kernelENS_9FwdParamsE"]
 
 
 def main():

@@ -13,8 +13,8 @@ initialisation fault.
 
     python tools/fuzz_kernels.py --causal [--iters 300]
 
-The same for the causal mask: the one-wave-per-SIMD kernel with the mask (FA_CAUSAL_W64=1: wherever it can
-run) against the general kernel (FA_CAUSAL_W64=0), L = 64k from 192 up and B*H up to 400 so that workgroups
+The same for the causal mask: the one-wave-per-SIMD kernel with the mask (FA_MASKED_W64=1: wherever it can
+run) against the general kernel (FA_MASKED_W64=0), L = 64k from 192 up and B*H up to 400 so that workgroups
 walk several items of different lengths.  Each must repeat itself bit for bit; they may differ from each
 other by the rounding of the result."""
 import argparse, os, sys
@@ -34,7 +34,7 @@ cpu = torch.Generator().manual_seed(args.seed)
 envs = [{"FA_W64": "1"}, {"FA_W64": "0"}, {"FA_W64": "0", "FA_RING": "0"}]  # (FA_W64=1: from three tiles on)
 
 if args.causal:
-    envs = [{"FA_CAUSAL_W64": "1"}, {"FA_CAUSAL_W64": "0"}, {"FA_CAUSAL_W64": "0"}]
+    envs = [{"FA_MASKED_W64": "1"}, {"FA_MASKED_W64": "0"}, {"FA_MASKED_W64": "0"}]
 
 def run(q, k, v, env):
     for a, b in env.items():
