@@ -500,30 +500,35 @@ __device__ __forceinline__ void decode_item_causal(const FwdParams& p, int item,
 //   lo  = (rows at the head of the tile that repeat the tile before) - 4 hh            (ragged last tile; else 0)
 // Masked scores become -inf (their exponential is 0 and they leave the row max alone); mx is recomputed
 // from what stays (-inf for a row that sees nothing of the tile).
+// (LO = false: no lower bound, one comparison per score: the diagonal tiles of a causal sequence in whole tiles,
+// several per item, sit on the critical path of short sequences.)
+template <bool LO>
 __device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int thr, int lo, float& mx, float c) {
     const float ninf = -__builtin_inff();
     float a = ninf;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int kc = 8 * (e >> 2) + (e & 3);
-        s0[e] = (kc > thr || kc < lo) ? ninf : s0[e];
-        s1[e] = (kc + 32 > thr || kc + 32 < lo) ? ninf : s1[e];
+        s0[e] = (kc > thr || (LO && kc < lo)) ? ninf : s0[e];
+        s1[e] = (kc + 32 > thr || (LO && kc + 32 < lo)) ? ninf : s1[e];
         a = fmaxf(fmaxf(a, s0[e]), s1[e]);
     }
     mx = half_wave_max(a) * c;
 }
 
-// MASKED = false: whole tiles, no mask (lq % 64 == 0, lk % 64 == 0): the default kernel.
-// MASKED = true adds, without touching the phases:
-//   * the causal mask (kFlagCausal; lq == lk, positions from 0): per-item tile counts, the item order above;
-//   * any lk >= 192: the last tile's source is shifted down to end at the last key, so it repeats
-//     dup = 64 n_tiles - lk rows of the tile before, which are masked;
-//   * any lq >= 64: a wave whose 64 rows would pass the end takes the last 64 rows instead and stores only
-//     the rows no other wave owns (the others are computed twice and stored once).
+// <false, false>: whole tiles, no mask (lq % 64 == 0, lk % 64 == 0): the default kernel.  Without touching the
+// phases,
+//   CAUSAL adds the causal mask (lq == lk, positions from 0): per-item tile counts, the item order above;
+//   RAGGED adds any lk >= 192: the last tile's source is shifted down to end at the last key, so it repeats
+//     dup = 64 n_tiles - lk rows of the tile before, which are masked; and any lq >= 64: a wave whose 64 rows
+//     would pass the end takes the last 64 rows instead and stores only the rows no other wave owns (the
+//     others are computed twice and stored once).
 // A tile the diagonal touches or the ragged last tile gets mask_scores() in a cold branch between two phases.
-template <bool MASKED>
+// (Four instantiations rather than run-time flags: the kernel has no scalar registers to spare, and the
+// bookkeeping of both features together already spills some of them to vector lanes.)
+template <bool CAUSAL, bool RAGGED>
 __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
-    constexpr bool CAUSAL = MASKED;  // (per-item tile counts and item order: compiled in with the mask)
+    constexpr bool MASKED = CAUSAL || RAGGED;
     constexpr int NWAVES = 4;
     constexpr int QB = 256;                        // query rows per item
     constexpr int kImgBytes = 64 * kRowBytes;      // staging image per wave: 64 rows
@@ -560,28 +565,24 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     for (int i = 0; i < 4; ++i) w.v_ad[i] = v_lds + (unsigned)g.v_rd[i];
 
     const int n_items = p.bh * p.q_blocks;
-    const int n_tiles_all = MASKED ? (p.lk + kKvTile - 1) / kKvTile : p.lk / kKvTile;  // >= 3
-    [[maybe_unused]] const bool causal = MASKED && (p.flags & kFlagCausal) != 0;
-    [[maybe_unused]] const int dup = MASKED ? n_tiles_all * kKvTile - p.lk : 0;
+    const int n_tiles_all = RAGGED ? (p.lk + kKvTile - 1) / kKvTile : p.lk / kKvTile;  // >= 3
+    constexpr bool causal = CAUSAL;
+    [[maybe_unused]] const int dup = RAGGED ? n_tiles_all * kKvTile - p.lk : 0;
     const int stride = (int)gridDim.x;
     // tiles of an item: all of them, or with the mask those up to the query block's diagonal (>= 3 as well)
     auto item_tiles = [&](int blk) -> int {
         if constexpr (CAUSAL) {
             const int n = 4 * (blk + 1);
-            return (causal && n < n_tiles_all) ? n : n_tiles_all;
+            return n < n_tiles_all ? n : n_tiles_all;
         } else {
             return n_tiles_all;
         }
     };
     auto decode = [&](int it, int& hd, int& blk) {
-        if constexpr (CAUSAL) {
-            if (causal)
-                decode_item_causal(p, it, stride, hd, blk);
-            else
-                decode_item(p, it, hd, blk);
-        } else {
+        if constexpr (CAUSAL)
+            decode_item_causal(p, it, stride, hd, blk);
+        else
             decode_item(p, it, hd, blk);
-        }
     };
     const float c = p.scale_log2e;
     constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
@@ -599,7 +600,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         if (__builtin_expect((cur_).tile + 1 < (CAUSAL ? (cur_).nt : n_tiles_all), 1)) {       \
             ++(cur_).tile;                                                                     \
             (cur_).off += kTileElems;                                                          \
-            if (MASKED && (cur_).tile == n_tiles_all - 1) (cur_).off -= (size_t)dup * kHeadDim; \
+            if (RAGGED && (cur_).tile == n_tiles_all - 1) (cur_).off -= (size_t)dup * kHeadDim; \
         } else if ((cur_).item + stride < n_items) {                                           \
             (cur_).item += stride;                                                             \
             (cur_).tile = 0;                                                                   \
@@ -642,32 +643,38 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     auto row_pos = [&](int blk) -> int {
         int r0 = blk * QB + wave * 64;
         if (r0 >= p.lq) r0 = blk * QB;
-        if constexpr (MASKED)
+        if constexpr (RAGGED)
             if (r0 > p.lq - 64) r0 = p.lq - 64;
         return r0;
     };
     auto source_row = [&](int hd, int blk) -> size_t { return (size_t)hd * p.lq + (size_t)row_pos(blk); };
     auto owns_rows = [&](int blk) -> bool { return blk * QB + wave * 64 < p.lq; };
-    // rows at the head of the wave's 64 that another wave owns (MASKED, last rows of a ragged sequence)
+    // rows at the head of the wave's 64 that another wave owns (RAGGED, last rows of the sequence)
     [[maybe_unused]] auto rows_skipped = [&](int blk) -> int { return blk * QB + wave * 64 - row_pos(blk); };
     size_t wrow = source_row(head, qb);  // this wave's first query row
     Cursor kc = {item, 0, n_tiles, (size_t)head * p.lk * kHeadDim};
     // Causal mask: `lim` is the position of the wave's first query row (in keys); a tile whose last key
     // lies beyond a sub-block's first row takes the mask (mask_scores, between the phases).
     [[maybe_unused]] int lim = row_pos(qb);
-    // mask_if_needed(s0, s1, mx, tile, pos): the scores of tile `tile` for the sub-block whose first row has
-    // position pos; true if they were masked (mx is then the new row max)
-    [[maybe_unused]] auto mask_if_needed = [&](f32x16& s0, f32x16& s1, float& mx, int tile, int pos) -> bool {
-        const bool tail = dup != 0 && tile == n_tiles_all - 1;
+    // needs_mask(tile, pos): does tile `tile` need a mask for the sub-block whose first row has position pos
+    // (wave-uniform; the ragged last tile, or a tile the diagonal touches)?  apply_mask() then masks the
+    // scores and recomputes their row max.  The call sites mark the branch unlikely, which keeps the mask
+    // code out of the steady-state loop's layout.
+    [[maybe_unused]] auto needs_mask = [&](int tile, int pos) -> bool {
+        const bool tail = RAGGED && dup != 0 && tile == n_tiles_all - 1;
         const int key0 = tail ? p.lk - kKvTile : kKvTile * tile;
-        const bool diag = causal && key0 + 63 > pos;
-        if (__builtin_expect(!(tail || diag), 1)) return false;
+        return tail || (causal && key0 + 63 > pos);
+    };
+    [[maybe_unused]] auto apply_mask = [&](f32x16& s0, f32x16& s1, float& mx, int tile, int pos) {
+        const bool tail = RAGGED && dup != 0 && tile == n_tiles_all - 1;
+        const int key0 = tail ? p.lk - kKvTile : kKvTile * tile;
         const int l_ = opaque(lane);
         const int r_ = l_ & 31, h4_ = 4 * (l_ >> 5);
-        mask_scores(s0, s1, causal ? pos + r_ - key0 - h4_ : 1000, (tail ? dup : 0) - h4_, mx, c);
-        return true;
+        if (tail)
+            mask_scores<true>(s0, s1, causal ? pos + r_ - key0 - h4_ : 1000, dup - h4_, mx, c);
+        else
+            mask_scores<false>(s0, s1, pos + r_ - key0 - h4_, 0, mx, c);
     };
-
     // ---- prologue, in three groups so that the first scores start on as little data as possible:
     //        Q_A rows, K(0)            | waited for first: S_A(0) needs nothing else
     //        Q_B rows, K(1), V(0)      | waited for before step 0 (behind S_A(0) and the state set-up)
@@ -709,7 +716,8 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // S_A(0) and its state; P_B = 0 makes the first phase's O_B update a no-op on values that
     // init_state replaces anyway, and S_B needs no value before phase 1 writes it.
     first_scores<kQregA>(w, kb0, kb1, sa0, sa1, mx_a, c);
-    if constexpr (MASKED) mask_if_needed(sa0, sa1, mx_a, 0, lim);
+    if constexpr (MASKED)
+        if (needs_mask(0, lim)) apply_mask(sa0, sa1, mx_a, 0, lim);
     {
         f32x16 o[4];
         init_state(p, wrow + g.r, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
@@ -734,7 +742,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // first row of the item whose O_A / O_B is being accumulated (O_B holds none before the stream's
     // first phase 1)
     size_t out_a = owns_rows(qb) ? wrow : kNoRows, out_b = kNoRows;
-    [[maybe_unused]] int skip_a = MASKED ? rows_skipped(qb) : 0, skip_b = 0;  // of the items out_a / out_b name
+    [[maybe_unused]] int skip_a = RAGGED ? rows_skipped(qb) : 0, skip_b = 0;  // of the items out_a / out_b name
 
 #define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_)                                     \
     do {                                                                                       \
@@ -746,7 +754,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
                 finish_rows(p, r_ + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);    \
             else                                                                               \
                 store_output_rows(p.o + r_ * kHeadDim, (img_), lane, o_, (st_).l_run,          \
-                                  MASKED ? (skip_) - (int)(off_) : 0);                         \
+                                  RAGGED ? (skip_) - (int)(off_) : 0);                         \
         }                                                                                      \
     } while (0)
     // Start of an item for one sub-block, given the scaled row max mx_ of its first tile.  A fresh item
@@ -819,13 +827,16 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
         if constexpr (MASKED) {
             // S_B(t): rows lim + 32 .. lim + 63 against tile t
-            if (mask_if_needed(sb0, sb1, mx_b, t, lim + 32)) need_b = rescale_needed(mx_b, rb.m_run);
+            if (__builtin_expect(needs_mask(t, lim + 32), 0)) {
+                apply_mask(sb0, sb1, mx_b, t, lim + 32);
+                need_b = rescale_needed(mx_b, rb.m_run);
+            }
         }
         if (__builtin_expect(first, 0)) {
             // O_B of the previous item is complete: write it out, then start the new item's state
             W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b);
             out_b = owns_rows(qb) ? wrow : kNoRows;
-            if constexpr (MASKED) skip_b = rows_skipped(qb);
+            if constexpr (RAGGED) skip_b = rows_skipped(qb);
             W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b);
         }
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
@@ -841,8 +852,11 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
         if constexpr (MASKED) {
             // S_A(t+1), or in an item's last step S_A(0) of the next item: rows lim .. lim + 31
-            if (mask_if_needed(sa0, sa1, mx_a, last ? 0 : t + 1, last ? row_pos(nqb) : lim))
+            const int tile_a = last ? 0 : t + 1, pos_a = last ? row_pos(nqb) : lim;
+            if (__builtin_expect(needs_mask(tile_a, pos_a), 0)) {
+                apply_mask(sa0, sa1, mx_a, tile_a, pos_a);
                 need_a = rescale_needed(mx_a, ra.m_run);
+            }
         }
         if (__builtin_expect(last, 0)) {
             W64_WRITE_OUT(kAccA, ra, out_a, 0, img, skip_a);
@@ -863,7 +877,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
                 return true;
             }
             out_a = owns_rows(nqb) ? nwrow : kNoRows;
-            if constexpr (MASKED) skip_a = rows_skipped(nqb);
+            if constexpr (RAGGED) skip_a = rows_skipped(nqb);
             W64_INIT(kAccA, ra, nwrow, mx_a, need_a);
         }
         rescale_if_needed<kAccA>(need_a, mx_a, ra);
@@ -880,10 +894,8 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             head = nhead;
             qb = nqb;
             wrow = nwrow;
-            if constexpr (MASKED) {
-                n_tiles = item_tiles(qb);
-                lim = row_pos(qb);
-            }
+            if constexpr (CAUSAL) n_tiles = item_tiles(qb);
+            if constexpr (MASKED) lim = row_pos(qb);
             t = -1;
         }
         ++t;
@@ -896,9 +908,14 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) { fa_fwd_w64_body<false>(p); }
-// The same with masks: the causal mask (kFlagCausal), sequence lengths that are not whole tiles.
-__global__ __launch_bounds__(256, 1) void fa_fwd_w64_masked_kernel(const FwdParams p) { fa_fwd_w64_body<true>(p); }
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) { fa_fwd_w64_body<false, false>(p); }
+// The same with the causal mask, lengths in whole tiles.
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_causal_kernel(const FwdParams p) { fa_fwd_w64_body<true, false>(p); }
+// The same for lengths that are not whole tiles, without and with the causal mask.
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_kernel(const FwdParams p) { fa_fwd_w64_body<false, true>(p); }
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_causal_kernel(const FwdParams p) {
+    fa_fwd_w64_body<true, true>(p);
+}
 
 #undef W64_ADVANCE
 #undef W64_DMA_K

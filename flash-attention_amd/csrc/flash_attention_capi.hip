@@ -189,6 +189,12 @@ bool masked_on_w64(int flags, int D, int lq, int lk) {
     if (const char* e = std::getenv("FA_MASKED_W64")) return std::atoi(e) != 0;
     return causal ? (lq >= 512 || lq == 256) : lk >= 5 * fa::kKvTile;
 }
+// (which of its instantiations: by the mask flag and by whether both lengths are whole tiles)
+const char* masked_w64_name(const fa::FwdParams& p) {
+    const bool ragged = p.lq % fa::kKvTile != 0 || p.lk % fa::kKvTile != 0;
+    if (p.flags & fa::kFlagCausal) return ragged ? "fa::fa_fwd_w64_ragged_causal_kernel" : "fa::fa_fwd_w64_causal_kernel";
+    return "fa::fa_fwd_w64_ragged_kernel";
+}
 int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
     fa::FwdParams p = base;  // flags: the state bits and kFlagCausal
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
@@ -197,7 +203,16 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
     if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "masked kernel: grid size out of range%s");
     long grid = (long)device_cus();
     if (grid > items) grid = items;
-    hipLaunchKernelGGL(fa::fa_fwd_w64_masked_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const bool ragged = p.lq % fa::kKvTile != 0 || p.lk % fa::kKvTile != 0;
+    const dim3 g((unsigned)grid), b(256);
+    if (p.flags & fa::kFlagCausal) {
+        if (ragged)
+            hipLaunchKernelGGL(fa::fa_fwd_w64_ragged_causal_kernel, g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL(fa::fa_fwd_w64_causal_kernel, g, b, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(fa::fa_fwd_w64_ragged_kernel, g, b, 0, stream, p);
+    }
     FA_HIP(hipGetLastError());
     return FA_OK;
 }
@@ -295,14 +310,18 @@ const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pic
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
         case kRouteTuned: return fa_kernel_name(lq, lk);
-        case kRouteCausalW64: return "fa::fa_fwd_w64_masked_kernel";
+        case kRouteCausalW64: return "fa::fa_fwd_w64_causal_kernel";
         default: return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
     }
 }
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
     if (flags == 0 && D == fa::kHeadDim && lq > 0 && lk > 0 && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0)
         return fa_kernel_name(lq, lk);
-    if (masked_on_w64(flags, D, lq, lk)) return "fa::fa_fwd_w64_masked_kernel";
+    if (masked_on_w64(flags, D, lq, lk)) {
+        fa::FwdParams p{};
+        p.lq = lq, p.lk = lk, p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
+        return masked_w64_name(p);
+    }
     return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
 }
 

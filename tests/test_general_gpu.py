@@ -98,7 +98,16 @@ def test_long_causal_row_subset(fa, oracle, dev):
     gate(oracle, ref, O[:, :, rows], "long causal rows")
 
 
-CAUSAL_TUNED = b"fa::fa_fwd_w64_masked_kernel"
+CAUSAL_TUNED = b"fa::fa_fwd_w64_causal_kernel"
+
+
+def masked_tuned(Lq, Lk, causal):
+    """Name of the one-wave-per-SIMD kernel's masked instantiation for a shape."""
+    ragged = Lq % 64 != 0 or Lk % 64 != 0
+    if causal:
+        return b"fa::fa_fwd_w64_ragged_causal_kernel" if ragged else CAUSAL_TUNED
+    assert ragged
+    return b"fa::fa_fwd_w64_ragged_kernel"
 
 
 def test_masked_kernel_choice(fa, monkeypatch):
@@ -109,19 +118,19 @@ def test_masked_kernel_choice(fa, monkeypatch):
     general = b"fa::fa_fwd_general_kernel<128>"
     monkeypatch.delenv("FA_MASKED_W64", raising=False)
     for L in (256, 512, 576, 700, 16383, 16384):
-        assert name(L, L, 128, 1) == CAUSAL_TUNED
+        assert name(L, L, 128, 1) == masked_tuned(L, L, True)
     for L in (64, 128, 192, 320, 448, 500):
         assert name(L, L, 128, 1) == general
     for Lq, Lk in ((511, 511), (64, 321), (100, 4000), (2047, 2047), (300, 320)):
-        assert name(Lq, Lk, 128, 0) == CAUSAL_TUNED
+        assert name(Lq, Lk, 128, 0) == masked_tuned(Lq, Lk, False)
     for Lq, Lk in ((63, 1000), (511, 300), (1, 5000), (200, 319)):
         assert name(Lq, Lk, 128, 0) == general
     assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>" and name(511, 511, 256, 0).endswith(b"<256>")
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
     monkeypatch.setenv("FA_MASKED_W64", "1")
     for L in (192, 320, 448, 200, 500):
-        assert name(L, L, 128, 1) == CAUSAL_TUNED
-    assert name(64, 193, 128, 0) == CAUSAL_TUNED
+        assert name(L, L, 128, 1) == masked_tuned(L, L, True)
+    assert name(64, 193, 128, 0) == masked_tuned(64, 193, False)
     assert name(128, 128, 128, 1) == general and name(63, 500, 128, 0) == general and name(100, 191, 128, 0) == general
     monkeypatch.setenv("FA_MASKED_W64", "0")
     assert name(512, 512, 128, 1) == general and name(511, 511, 128, 0) == general
@@ -174,7 +183,7 @@ def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, mon
     key (its repeated rows masked), a wave whose rows would pass the last query row takes the last 64 rows and
     stores only its own.  NaN-padded inputs and a sentinel-padded output catch reads and writes past the end."""
     monkeypatch.setenv("FA_MASKED_W64", "1")
-    assert fa.lib().fa_kernel_name_general(Lq, Lk, 128, int(causal)) == CAUSAL_TUNED
+    assert fa.lib().fa_kernel_name_general(Lq, Lk, 128, int(causal)) == masked_tuned(Lq, Lk, causal)
     rng = np.random.default_rng(Lq * 7 + Lk)
     B, H = 2, 3
     Q = rng.standard_normal((B, H, Lq, 128), dtype=np.float32).astype(np.float16)
@@ -199,7 +208,7 @@ def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, monkey
     import torch
 
     monkeypatch.delenv("FA_MASKED_W64", raising=False)
-    assert fa.lib().fa_kernel_name_general(L, L, 128, int(causal)) == CAUSAL_TUNED
+    assert fa.lib().fa_kernel_name_general(L, L, 128, int(causal)) == masked_tuned(L, L, causal)
     Q, K, V = normal_fp16(500 + L, (B, H, L, 128))
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
     o = torch.full_like(q, float("nan"))

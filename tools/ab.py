@@ -28,6 +28,8 @@ def main():
                     help="seconds of untimed launches per shape before timing (the chip's clock needs sustained load to settle)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--causal", action="store_true", help="fa_forward_general with the causal mask instead of fa_forward")
+    ap.add_argument("--lminus", type=int, default=0, help="shorten every L by this much (ragged lengths, fa_forward_general)")
     ap.add_argument("--data", choices=["pattern", "normal"], default="pattern",
                     help="pattern = the reference driver's init_half; normal = N(0,1) rounded to fp16")
     args = ap.parse_args()
@@ -45,6 +47,9 @@ def main():
         L = ct.CDLL(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
         L.fa_forward.argtypes = sig
         L.fa_forward.restype = ct.c_int
+        if args.causal or args.lminus:
+            L.fa_forward_general.argtypes = [HalfPtr] * 4 + [ct.c_int] * 6 + [ct.c_void_p, ct.POINTER(ct.c_float)]
+            L.fa_forward_general.restype = ct.c_int
         for e in envs:
             name = os.path.basename(path) + ("" if not e else "[" + ",".join(f"{k}={v}" for k, v in e.items()) + "]")
             variants.append((name, L, e))
@@ -69,14 +74,18 @@ def main():
         name, lib, e = variants[i]
         for kk, vv in e.items():
             os.environ[kk] = vv
-        rc = lib.fa_forward(p(q), p(k), p(v), p(outs[i]), B, H, L, D, 64, stream, None)
+        if args.causal or args.lminus:
+            rc = lib.fa_forward_general(p(q), p(k), p(v), p(outs[i]), B, H, L, L, D, int(args.causal), stream, None)
+        else:
+            rc = lib.fa_forward(p(q), p(k), p(v), p(outs[i]), B, H, L, D, 64, stream, None)
         for kk in e:
             os.environ.pop(kk, None)
         assert rc == 0, (name, rc)
 
     for L in args.shapes:
         B = max(1, 16384 // L)
-        flops = 4.0 * B * H * L * L * D
+        L -= args.lminus
+        flops = 2.0 * B * H * L * (L + 1) * D if args.causal else 4.0 * B * H * L * L * D
         times = [[] for _ in variants]
         for i in range(len(variants)):
             for _ in range(5):

@@ -5,7 +5,7 @@
 
 Pattern data of the reference's throughput driver, 1 s of preheat, back-to-back launches between two
 events.  FLOPs: 4*B*H*Lq*Lk*D without mask, half of that (the visible triangle, diagonal included:
-2*B*H*L*(L+1)*D) with the causal mask.  --causal-sweep: the two causal kernels side by side over L."""
+2*B*H*L*(L+1)*D) with the causal mask.  --causal-sweep / --ragged-sweep: the masked tuned kernel and the general kernel side by side over L."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,7 +20,10 @@ for t, seed in zip(buf[:3], (1234, 2345, 3456)):
     fa.init_half(t, seed)
 
 def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
-    os.environ["FA_MASKED_W64"] = "1" if tuned_causal else "0"
+    """tuned_causal: None = the library's own choice, True / False = FA_MASKED_W64=1 / 0"""
+    os.environ.pop("FA_MASKED_W64", None)
+    if tuned_causal is not None:
+        os.environ["FA_MASKED_W64"] = "1" if tuned_causal else "0"
     m = B * H * L * D
     q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
     f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))
@@ -41,10 +44,19 @@ def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
 
 for B, L in ((32, 512), (8, 2048), (1, 16384)):
     run("tuned kernel, no mask", B, L, False, general=False)
-    run("general kernel, no mask, L-1 (ragged tail)", B, L - 1, False)
-    run("tuned kernel, causal", B, L, True)
+    run("masked tuned kernel, no mask, L-1 (ragged)", B, L - 1, False)
+    run("general kernel, no mask, L-1 (ragged)", B, L - 1, False, tuned_causal=False)
+    run("masked tuned kernel, causal", B, L, True)
     run("general kernel, causal", B, L, True, tuned_causal=False)
-    run("general kernel, causal, L-1", B, L - 1, True)
+    run("masked tuned kernel, causal, L-1", B, L - 1, True)
+    run("general kernel, causal, L-1", B, L - 1, True, tuned_causal=False)
+if "--ragged-sweep" in sys.argv:
+    for L in (193, 257, 321, 385, 449, 511, 577, 767, 1023):
+        B = max(1, 16384 // L)
+        for causal in (False, True):
+            run(f"masked tuned kernel, causal={causal}", B, L, causal)
+            run(f"general kernel, causal={causal}", B, L, causal, tuned_causal=False)
+    sys.exit(0)
 if "--causal-sweep" in sys.argv:
     for L in (256, 320, 384, 512, 768, 1024, 2048, 4096, 8192, 16384):
         B = max(1, 16384 // L)

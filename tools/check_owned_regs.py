@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Build-time audit of fa_fwd_w64_kernel and fa_fwd_w64_masked_kernel, whose inline asm owns the accumulator registers.
+"""Build-time audit of fa_fwd_w64_kernel and its masked forms (causal, ragged, both), whose inline asm owns the accumulator registers.
 
 The kernel names a[0:255] literally in its instruction strings; the compiler does not know they hold
 live values.  That is only sound while the compiler itself uses no accumulator register and spills
 nothing in that kernel.  This script compiles the library's device code to assembly and fails if
-either kernel has scratch, spills, or any v_accvgpr_* / a[..] operand outside the #ASMSTART/#ASMEND
+any of them has scratch, spills, or any v_accvgpr_* / a[..] operand outside the #ASMSTART/#ASMEND
 blocks.
 
     python tools/check_owned_regs.py [extra hipcc flags...]
@@ -17,7 +17,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "flash-attention_amd", "csrc", "flash_attention_capi.hip")
-KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_masked_kernelENS_9FwdParamsE"]
+KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causal_kernelENS_9FwdParamsE",
+           "_ZN2fa24fa_fwd_w64_ragged_kernelENS_9FwdParamsE", "_ZN2fa31fa_fwd_w64_ragged_causal_kernelENS_9FwdParamsE"]
 
 
 def main():
@@ -56,6 +57,9 @@ def audit(text, KERNEL):
         mm = re.search(key + r"\s+(\d+)", meta)
         if mm and int(mm.group(1)) != 0:
             problems.append(f"{key} = {mm.group(1)}")
+    lanes = len(re.findall(r"\bv_(?:read|write)lane_b32", m.group(0)))
+    if lanes:
+        print(f"check_owned_regs: note: {KERNEL} keeps scalar values in vector lanes ({lanes} v_readlane/v_writelane)")
     if problems:
         print("check_owned_regs: FAILED for", KERNEL)
         for p in problems[:20]:
