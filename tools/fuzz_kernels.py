@@ -13,10 +13,10 @@ initialisation fault.
 
     python tools/fuzz_kernels.py --causal [--iters 300]
 
-The same for the causal mask: the one-wave-per-SIMD kernel with the mask (FA_MASKED_W64=1: wherever it can
-run) against the general kernel (FA_MASKED_W64=0), L = 64k from 192 up and B*H up to 400 so that workgroups
-walk several items of different lengths.  Each must repeat itself bit for bit; they may differ from each
-other by the rounding of the result."""
+The same for the masked forms of the one-wave-per-SIMD kernel (FA_MASKED_W64=1: wherever they can run)
+against the general kernel (FA_MASKED_W64=0): with and without the causal mask, L from 192 up (half of the
+cases not a multiple of 64) and B*H up to 400 so that workgroups walk several items of different lengths.
+Each must repeat itself bit for bit; they may differ from each other by the rounding of the result."""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,7 +41,7 @@ def run(q, k, v, env):
         os.environ[a] = b
     try:
         if args.causal and env:
-            return fa.attention_general(q, k, v, causal=True)
+            return fa.attention_general(q, k, v, causal=mask)
         return fa.attention(q, k, v)
     finally:
         for a in env:
@@ -53,9 +53,13 @@ for it in range(args.iters):
     B = int(torch.randint(1, 5, (1,), generator=cpu))
     H = int(torch.randint(1, 21, (1,), generator=cpu))
     L = 64 * int(torch.randint(1, 97, (1,), generator=cpu))  # (a partly filled last 256-row block in 3 of 4 cases)
+    mask = True
     if args.causal:
         L = 64 * int(torch.randint(3, 49, (1,), generator=cpu))
         H = int(torch.randint(1, 101, (1,), generator=cpu)) if L <= 1024 else H
+        mask = bool(torch.randint(0, 2, (1,), generator=cpu))
+        if not mask or bool(torch.randint(0, 2, (1,), generator=cpu)):
+            L += int(torch.randint(1, 64, (1,), generator=cpu))  # (without the mask only ragged lengths go there)
     scale = float(torch.rand(1, generator=cpu)) * 2.5 + 0.2
     q, k, v = [(torch.randn((B, H, L, 128), generator=g, device=dev) * scale + 0.3 * (i == 0)).to(torch.float16) for i in range(3)]
     outs = []
@@ -65,13 +69,22 @@ for it in range(args.iters):
         outs.append(run(q, k, v, env))
     torch.cuda.synchronize()
     a, b = outs[0].float(), outs[2].float()
-    close = bool(((a - b).abs() <= 2.0 ** -9 * torch.maximum(a.abs(), b.abs()) + 1e-6).all())
+    mag = torch.maximum(a.abs(), b.abs())
+    if args.causal and L % 64 != 0:
+        # Ragged lengths: the masked kernel cuts the keys into tiles differently (its last tile ends at the last
+        # key) and groups the last query rows differently, so a row's deferred-rescale reference point, and with
+        # it the fp16 rounding of its probabilities (2^-11 relative each), differs from the general kernel's.
+        # That noise scales with the row's values, not with the single output element: the bound is relative
+        # to the row's largest output.  (Both kernels sit at the same distance from the CPU oracle:
+        # tests/soak/diag_ragged.py.)
+        mag = mag.amax(dim=-1, keepdim=True)
+    close = bool(((a - b).abs() <= 2.0 ** -9 * mag + 1e-6).all())
     ok = (torch.equal(outs[0], outs[1]) and all(torch.equal(outs[2], o) for o in outs[3:]) and close
           and bool(torch.isfinite(a).all()))
     if not ok:
         bad += 1
         d = [float((outs[0].float() - o.float()).abs().max()) for o in outs]
-        print(f"iter {it}: B={B} H={H} L={L} scale={scale:.2f}: MISMATCH max|diff| per run {d}")
+        print(f"iter {it}: B={B} H={H} L={L} mask={mask} scale={scale:.2f}: MISMATCH max|diff| per run {d}")
     if it % 50 == 49:
         print(f"{it + 1} shapes, {bad} mismatches", flush=True)
 print("fuzz:", "FAILED" if bad else "ok", f"({args.iters} shapes, {bad} mismatches)")
