@@ -176,18 +176,22 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
     return FA_OK;
 }
 
-// The masked form of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
-// that are not whole tiles; it needs Lq >= 64 (a wave's rows) and three tiles of keys.  Measured against the
-// general kernel: with the mask it wins at L = 256 and from 512 up (between those a partly filled last block
-// of idle waves costs more than the general kernel's slower loop), without it from five tiles on, as the
-// unmasked kernel against the 8-wave one.  FA_MASKED_W64=1 takes it wherever it can run, FA_MASKED_W64=0
-// nowhere (A/B comparisons, tests).
+// The masked forms of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
+// that are not whole tiles; they need Lq >= 64 (a wave's rows) and three tiles of keys.  Against the general
+// kernel (128-row workgroups) they lose where the last 256-row query block is at most half full and the
+// sequence short, because its idle waves then weigh more than the faster loop gains.  Measured
+// (tools/bench_general.py --ragged-sweep --fine, B*L = 16384, H = 16): without the mask they win from
+// Lq = 512 on and below that with more than 128 rows in the last block; with the mask from Lq = 1088 on, from
+// 385 on with more than 128 rows in the last block, and at 192 and 256.  FA_MASKED_W64=1 takes them wherever
+// they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests).
 bool masked_on_w64(int flags, int D, int lq, int lk) {
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (D != fa::kHeadDim || lq < 64 || lk < 3 * fa::kKvTile || (causal && lq != lk)) return false;
     if (!causal && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return false;  // the unmasked kernels' shapes
     if (const char* e = std::getenv("FA_MASKED_W64")) return std::atoi(e) != 0;
-    return causal ? (lq >= 512 || lq == 256) : lk >= 5 * fa::kKvTile;
+    const int last_block_rows = (lq - 1) % 256 + 1;
+    if (!causal) return lq >= 512 || last_block_rows > 128;
+    return lq >= 1088 || (lq >= 385 && last_block_rows > 128) || lq == 192 || lq == 256;
 }
 // (which of its instantiations: by the mask flag and by whether both lengths are whole tiles)
 const char* masked_w64_name(const fa::FwdParams& p) {

@@ -111,24 +111,24 @@ def masked_tuned(Lq, Lk, causal):
 
 
 def test_masked_kernel_choice(fa, monkeypatch):
-    """D = 128 with the causal mask (Lq == Lk = 256 or from 512 up) or ragged lengths (Lq >= 64, Lk from five
-    tiles up): the masked form of the one-wave-per-SIMD kernel; everything else stays on the general kernel.
-    FA_MASKED_W64=1 extends it to every shape it can run (Lq >= 64, three tiles of keys)."""
+    """D = 128 with the causal mask or ragged lengths: the masked forms of the one-wave-per-SIMD kernel where they
+    were measured faster than the general kernel (long sequences, or a last 256-row block more than half full);
+    FA_MASKED_W64=1 extends them to every shape they can run (Lq >= 64, three tiles of keys)."""
     name = fa.lib().fa_kernel_name_general
     general = b"fa::fa_fwd_general_kernel<128>"
     monkeypatch.delenv("FA_MASKED_W64", raising=False)
-    for L in (256, 512, 576, 700, 16383, 16384):
+    for L in (192, 256, 448, 500, 512, 700, 1088, 16383, 16384):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
-    for L in (64, 128, 192, 320, 448, 500):
+    for L in (64, 128, 193, 320, 384, 576, 640, 1025):
         assert name(L, L, 128, 1) == general
-    for Lq, Lk in ((511, 511), (64, 321), (100, 4000), (2047, 2047), (300, 320)):
+    for Lq, Lk in ((511, 511), (2047, 2047), (193, 1000), (600, 320), (513, 513)):
         assert name(Lq, Lk, 128, 0) == masked_tuned(Lq, Lk, False)
-    for Lq, Lk in ((63, 1000), (511, 300), (1, 5000), (200, 319)):
+    for Lq, Lk in ((63, 1000), (511, 191), (1, 5000), (257, 512), (100, 4000), (321, 321)):
         assert name(Lq, Lk, 128, 0) == general
     assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>" and name(511, 511, 256, 0).endswith(b"<256>")
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
     monkeypatch.setenv("FA_MASKED_W64", "1")
-    for L in (192, 320, 448, 200, 500):
+    for L in (320, 200, 577):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
     assert name(64, 193, 128, 0) == masked_tuned(64, 193, False)
     assert name(128, 128, 128, 1) == general and name(63, 500, 128, 0) == general and name(100, 191, 128, 0) == general
@@ -201,7 +201,7 @@ def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, mon
     assert np.array_equal(O, O2)  # rows computed by two waves are stored by one: repeats are bit-exact
 
 
-@pytest.mark.parametrize("B,H,L,causal", [(9, 16, 1000, False), (7, 21, 575, True), (4, 16, 2100, True)])
+@pytest.mark.parametrize("B,H,L,causal", [(9, 16, 1000, False), (7, 21, 705, True), (4, 16, 2100, True)])
 def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, monkeypatch):
     """Several items per workgroup with ragged lengths: every row against the general kernel, sampled rows
     against the oracle."""

@@ -19,6 +19,9 @@ buf = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(4)]
 for t, seed in zip(buf[:3], (1234, 2345, 3456)):
     fa.init_half(t, seed)
 
+PREHEAT = 0.3 if "--fine" in sys.argv else 1.0
+
+
 def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
     """tuned_causal: None = the library's own choice, True / False = FA_MASKED_W64=1 / 0"""
     os.environ.pop("FA_MASKED_W64", None)
@@ -28,7 +31,7 @@ def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
     q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
     f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 1.0:
+    while time.perf_counter() - t0 < PREHEAT:
         for _ in range(10):
             f()
         torch.cuda.synchronize()
@@ -51,9 +54,12 @@ for B, L in ((32, 512), (8, 2048), (1, 16384)):
     run("masked tuned kernel, causal, L-1", B, L - 1, True)
     run("general kernel, causal, L-1", B, L - 1, True, tuned_causal=False)
 if "--ragged-sweep" in sys.argv:
-    for L in (193, 257, 321, 385, 449, 511, 577, 767, 1023):
+    Ls = [L for L0 in range(192, 1345, 64) for L in (L0, L0 + 1)] if "--fine" in sys.argv else (193, 257, 321, 385, 449, 511, 577, 767, 1023)
+    for L in Ls:
         B = max(1, 16384 // L)
         for causal in (False, True):
+            if not causal and L % 64 == 0:
+                continue
             run(f"masked tuned kernel, causal={causal}", B, L, causal)
             run(f"general kernel, causal={causal}", B, L, causal, tuned_causal=False)
     sys.exit(0)
