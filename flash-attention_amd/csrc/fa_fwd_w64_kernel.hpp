@@ -39,6 +39,10 @@
 // right after the phase that finished it.  The kernel needs lq % 64 == 0 (in a last block of fewer than
 // 256 rows some waves have no rows of their own: they compute along on a stand-in and store nothing)
 // and at least 3 tiles per item; the launcher sends other shapes to the other kernels.
+//
+// The body is a template: fa_fwd_w64_kernel is its plain form; the causal mask and lengths that are not
+// whole tiles are two template parameters that add per-item tile counts, a shifted last tile and a mask
+// applied between the phases (see fa_fwd_w64_body), and leave the phases as they are.
 #pragma once
 #include <type_traits>
 #include <utility>

@@ -101,7 +101,9 @@ int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
  * kernel has no mask; README.md:44-47 lists them as future work.
  *   dQ, dO  [B][H][Lq][D] fp16        dK, dV  [B][H][Lk][D] fp16        scale 1/sqrt(D)
  * Shapes the tuned kernels take (D == 128, Lq == Lk, a multiple of 64, no flags) are passed on to
- * fa_forward.  Asynchronous on `stream` unless elapsed_ms is non-NULL (as fa_forward). */
+ * fa_forward; other D == 128 shapes (the causal mask, lengths that are not multiples of 64, Lq != Lk)
+ * run on masked forms of the same kernel where those are faster than the general one
+ * (fa_kernel_name_general tells).  Asynchronous on `stream` unless elapsed_ms is non-NULL (as fa_forward). */
 enum { FA_FLAG_CAUSAL = 1 };
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream, float* elapsed_ms);
