@@ -743,10 +743,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     __syncthreads();
     q_install<kQregB>(img + 32 * kRowBytes, lane);
 
-    // first row of the item whose O_A / O_B is being accumulated (O_B holds none before the stream's
-    // first phase 1)
-    size_t out_a = owns_rows(qb) ? wrow : kNoRows, out_b = kNoRows;
-    [[maybe_unused]] int skip_a = RAGGED ? rows_skipped(qb) : 0, skip_b = 0;  // of the items out_a / out_b name
+    // first row of the item whose O_B is being accumulated (none before the stream's first phase 1; during an
+    // item's first phase 1 still the previous item).  O_A always belongs to the current item when it is written.
+    size_t out_b = kNoRows;
+    [[maybe_unused]] int skip_b = 0;  // rows_skipped() of the item out_b names
 
 #define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_)                                     \
     do {                                                                                       \
@@ -863,7 +863,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             }
         }
         if (__builtin_expect(last, 0)) {
-            W64_WRITE_OUT(kAccA, ra, out_a, 0, img, skip_a);
+            W64_WRITE_OUT(kAccA, ra, (owns_rows(qb) ? wrow : kNoRows), 0, img, rows_skipped(qb));
             if (!more_items) {
                 // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
                 pv_only<kAccB>(pb);
@@ -880,8 +880,6 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #endif
                 return true;
             }
-            out_a = owns_rows(nqb) ? nwrow : kNoRows;
-            if constexpr (RAGGED) skip_a = rows_skipped(nqb);
             W64_INIT(kAccA, ra, nwrow, mx_a, need_a);
         }
         rescale_if_needed<kAccA>(need_a, mx_a, ra);
