@@ -5,7 +5,10 @@
 // metrics and ten sample pairs.  Differences: the CPU reference comes from the
 // oracle library instead of being defined in this file, optional B H L
 // arguments, and a real exit status (non-zero when max-abs > 2e-3 or the
-// global relative error > 1e-3).
+// global relative error > 1e-3).  A fourth argument of 1 turns on the causal
+// mask that the reference's attention_cpu has (testing.cu:41-48,74-77) and its
+// GPU kernel lacks; with it, or with an L that is not a multiple of 64, the
+// call goes through fa_forward_general_host_half.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -27,6 +30,7 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? std::atoi(argv[1]) : 1;
     const int H = argc > 2 ? std::atoi(argv[2]) : 1;
     const int L = argc > 3 ? std::atoi(argv[3]) : 64;
+    const int causal = argc > 4 ? std::atoi(argv[4]) : 0;
     const int D = 128;
     const int tile = 64;
     const size_t n = (size_t)B * H * L * D;
@@ -43,12 +47,20 @@ int main(int argc, char** argv) {
     }
 
     float elapsed_ms = 0.0f;
-    run_tensor_flash_attention_host_half(Qh.data(), Kh.data(), Vh.data(), Oh.data(), B, H, L, D, tile, 0, &elapsed_ms);
+    if (causal || L % tile != 0) {
+        if (fa_forward_general_host_half(Qh.data(), Kh.data(), Vh.data(), Oh.data(), B, H, L, L, D,
+                                         causal ? FA_FLAG_CAUSAL : 0, 0, &elapsed_ms) != FA_OK) {
+            std::printf("fa_forward_general_host_half failed: %s\n", fa_last_error());
+            return 2;
+        }
+    } else {
+        run_tensor_flash_attention_host_half(Qh.data(), Kh.data(), Vh.data(), Oh.data(), B, H, L, D, tile, 0, &elapsed_ms);
+    }
     std::printf("Kernel elapsed: %f ms\n", elapsed_ms);
 
     std::vector<float> O_gpu(n), O_cpu(n, 0.0f);
     for (size_t i = 0; i < n; ++i) O_gpu[i] = oracle_half_to_float(Oh[i]);
-    oracle_attention_cpu(Qh.data(), Kh.data(), Vh.data(), O_cpu.data(), B, H, L, D, 0, 0);
+    oracle_attention_cpu(Qh.data(), Kh.data(), Vh.data(), O_cpu.data(), B, H, L, D, causal, 0);
 
     double m[5];
     oracle_error_metrics(O_cpu.data(), O_gpu.data(), n, m);

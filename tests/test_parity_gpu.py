@@ -416,6 +416,10 @@ def test_cpp_correctness_driver():
     assert "Global Relative Error" in r.stdout and "PASS" in r.stdout
     r = subprocess.run([exe, "2", "3", "320"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the causal mask of attention_cpu and a length that is not a multiple of 64 (the general entry point)
+    for extra in (["2", "3", "512", "1"], ["1", "2", "1100", "1"], ["1", "2", "700", "0"]):
+        r = subprocess.run([exe] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (extra, r.stdout + r.stderr)
 
 
 def test_compare_impls_counterpart():
