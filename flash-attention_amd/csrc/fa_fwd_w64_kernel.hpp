@@ -754,9 +754,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             const size_t r_ = (row_) + (off_);                                                 \
             f32x16 o_[4];                                                                      \
             acc_load<base_>(o_);                                                               \
-            if (p.flags & kFlagStoreState)                                                     \
-                finish_rows(p, r_ + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);    \
-            else                                                                               \
+            if (p.flags & kFlagStoreState) {                                                   \
+                if (!RAGGED || (int)(off_) + g.r >= (skip_))                                   \
+                    finish_rows(p, r_ + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run); \
+            } else                                                                             \
                 store_output_rows(p.o + r_ * kHeadDim, (img_), lane, o_, (st_).l_run,          \
                                   RAGGED ? (skip_) - (int)(off_) : 0);                         \
         }                                                                                      \

@@ -222,19 +222,23 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
 }
 
 // Which kernel folds one block in fa_forward_block_general.  A block that needs no mask (no flag, or every key of
-// it at or before the first query row) and has the tuned kernels' shape goes to them; the diagonal block of
-// a causal sequence (same positions, same length) to the causal one-wave-per-SIMD kernel where that one is
-// chosen; everything else (ragged sizes, other head dims, blocks the diagonal crosses elsewhere, blocks
-// wholly above it) to the general kernel.  All of them carry the same state.  FA_BLOCK_TUNED=0 keeps
-// everything on the general kernel (A/B comparisons).
-enum BlockRoute { kRouteGeneral, kRouteTuned, kRouteCausalW64 };
+// it at or before the first query row) goes to the tuned kernels: the unmasked ones in whole tiles, the
+// ragged form otherwise (where masked_on_w64() picks it); the diagonal block of a causal sequence (same
+// positions, same length) to the causal forms likewise; everything else (other head dims, short blocks, blocks
+// the diagonal crosses elsewhere, blocks wholly above it) to the general kernel.  All of them carry the same
+// state.  FA_BLOCK_TUNED=0 keeps everything on the general kernel (A/B comparisons).
+enum BlockRoute { kRouteGeneral, kRouteTuned, kRouteMaskedW64, kRouteUnmaskedRaggedW64 };
 BlockRoute block_route(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
-    if (D != fa::kHeadDim || lq % fa::kKvTile != 0 || lk % fa::kKvTile != 0) return kRouteGeneral;
+    if (D != fa::kHeadDim) return kRouteGeneral;
     if (const char* e = std::getenv("FA_BLOCK_TUNED"))
         if (std::atoi(e) == 0) return kRouteGeneral;
+    const bool whole = lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0;
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
-    if (!causal || (long)k_pos0 + lk - 1 <= (long)q_pos0) return kRouteTuned;
-    if (q_pos0 == k_pos0 && masked_on_w64(flags, D, lq, lk)) return kRouteCausalW64;
+    if (!causal || (long)k_pos0 + lk - 1 <= (long)q_pos0) {
+        if (whole) return kRouteTuned;
+        return masked_on_w64(0, D, lq, lk) ? kRouteUnmaskedRaggedW64 : kRouteGeneral;
+    }
+    if (q_pos0 == k_pos0 && masked_on_w64(flags, D, lq, lk)) return kRouteMaskedW64;
     return kRouteGeneral;
 }
 
@@ -314,7 +318,12 @@ const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pic
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
         case kRouteTuned: return fa_kernel_name(lq, lk);
-        case kRouteCausalW64: return "fa::fa_fwd_w64_causal_kernel";
+        case kRouteUnmaskedRaggedW64: return "fa::fa_fwd_w64_ragged_kernel";
+        case kRouteMaskedW64: {
+            fa::FwdParams p{};
+            p.lq = lq, p.lk = lk, p.flags = fa::kFlagCausal;
+            return masked_w64_name(p);
+        }
         default: return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
     }
 }
@@ -413,7 +422,10 @@ int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint1
             p.flags &= ~fa::kFlagCausal;
             p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
             return launch(p, stream);
-        case kRouteCausalW64:
+        case kRouteUnmaskedRaggedW64:
+            p.flags &= ~fa::kFlagCausal;
+            return launch_w64_masked(p, stream);
+        case kRouteMaskedW64:
             return launch_w64_masked(p, stream);
         default:
             return launch_general(p, D, stream);

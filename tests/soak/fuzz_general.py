@@ -43,7 +43,7 @@ def within_gate(ref, out16):
 for it in range(args.iters if args.tiles else 0):
     B, H = int(rng.integers(1, 3)), int(rng.integers(1, 12))
     nchunk = int(rng.integers(1, 5))
-    sizes = [64 * int(rng.integers(1, 13)) if rng.integers(0, 4) else int(rng.integers(1, 300)) for _ in range(nchunk)]
+    sizes = [64 * int(rng.integers(1, 13)) if rng.integers(0, 2) else int(rng.integers(1, 1200)) for _ in range(nchunk)]
     cuts = np.concatenate([[0], np.cumsum(sizes)]).tolist()
     L = cuts[-1]
     scale = float(rng.uniform(0.3, 1.6))

@@ -384,6 +384,40 @@ def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, d
     assert float((out.float() - out_g.float()).abs().max()) <= 1e-3
 
 
+def test_blockwise_general_ragged_chunks_on_the_tuned_kernels(fa, oracle, dev, monkeypatch):
+    """Chunks that are not whole tiles: unmasked pairs on the ragged form of the tuned kernel, diagonal pairs on
+    the ragged causal form, carrying state (rows that two waves compute are stored by their owner only)."""
+    import torch
+
+    monkeypatch.delenv("FA_MASKED_W64", raising=False)
+    monkeypatch.delenv("FA_BLOCK_TUNED", raising=False)
+    name = fa.lib().fa_kernel_name_block_general
+    assert name(511, 700, 128, 1, 700, 0) == b"fa::fa_fwd_w64_ragged_kernel"           # below the diagonal
+    assert name(700, 700, 128, 1, 0, 0) == b"fa::fa_fwd_w64_ragged_causal_kernel"     # diagonal pair
+    assert name(600, 600, 128, 1, 0, 0) == b"fa::fa_fwd_general_kernel<128>"          # (last block a third full)
+    assert name(600, 600, 128, 0, 0, 0) == b"fa::fa_fwd_w64_ragged_kernel"
+    assert name(50, 600, 128, 0, 0, 0) == b"fa::fa_fwd_general_kernel<128>"            # fewer than 64 query rows
+    B, H = 1, 4
+    cuts = [0, 700, 1211, 1600, 1650]
+    L = cuts[-1]
+    Q, K, V = normal_fp16(91, (B, H, L, 128))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    rng = np.random.default_rng(8)
+    out = torch.full_like(q, float("nan"))
+    for qc in range(len(cuts) - 1):
+        qa, qe = cuts[qc], cuts[qc + 1]
+        qq = q[:, :, qa:qe].contiguous()
+        st = fa.BlockState(B * H, qe - qa, 128, dev)
+        order = list(rng.permutation(qc + 1))
+        for n, kc in enumerate(order):
+            ka, ke = cuts[kc], cuts[kc + 1]
+            o = fa.attention_block_general(qq, k[:, :, ka:ke].contiguous(), v[:, :, ka:ke].contiguous(), st,
+                                           last=(n == len(order) - 1), causal=True, q_pos0=qa, k_pos0=ka)
+        out[:, :, qa:qe] = o
+    torch.cuda.synchronize()
+    gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), out.cpu().numpy(), "ragged chunks, blockwise causal")
+
+
 def test_query_and_key_lengths_in_whole_tiles_go_to_the_tuned_kernels(fa, oracle, dev):
     assert fa.lib().fa_kernel_name_general(256, 1024, 128, 0) == b"fa::fa_fwd_w64_kernel"
     rng = np.random.default_rng(21)
