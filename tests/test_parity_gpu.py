@@ -407,6 +407,35 @@ def test_error_convention_of_drop_in_symbols():
     assert "tile must be 64" in r.stderr
 
 
+def test_device_pointer_entry_points_can_be_captured_in_a_graph(fa, torch_dev):
+    """With elapsed_ms == NULL the device-pointer entry points neither allocate nor synchronise, so a stream
+    capture may hold them: tuned, masked and general kernels captured once and replayed on new inputs give the
+    bits of the eager calls."""
+    import torch
+
+    def make(seed, L):
+        g = torch.Generator(device=torch_dev).manual_seed(seed)
+        return [torch.randn((2, 4, L, 128), generator=g, device=torch_dev).to(torch.float16) for _ in range(3)]
+
+    q, k, v = make(1, 512)
+    qr, kr, vr = make(3, 500)  # a ragged length: the masked form of the tuned kernel
+    outs = [torch.empty_like(q), torch.empty_like(q), torch.empty_like(qr)]
+    fa.attention(q, k, v, out=outs[0])  # first call outside the capture (it caches the device's CU count)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fa.attention(q, k, v, out=outs[0])
+        fa.attention_general(q, k, v, causal=True, out=outs[1])
+        fa.attention_general(qr, kr, vr, out=outs[2])
+    for t, new in zip((q, k, v, qr, kr, vr), make(2, 512) + make(4, 500)):
+        t.copy_(new)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], fa.attention(q, k, v))
+    assert torch.equal(outs[1], fa.attention_general(q, k, v, causal=True))
+    assert torch.equal(outs[2], fa.attention_general(qr, kr, vr))
+
+
 def test_cpp_correctness_driver():
     """The `testing` binary (counterpart of testing.cu) exits 0 and prints the five metrics."""
     exe = os.path.join(ROOT, "tests", "cpp", "testing")
