@@ -70,7 +70,9 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
     if step_fn is None or state_factory is None:
         import flash_attention_amd as fa
 
-        step_fn = step_fn or fa.attention_block
+        # the general blockwise entry point: any rows per rank and D of 64, 128 or 256; it hands D = 128 blocks
+        # to the tuned kernels (whole tiles, and ragged lengths where those win)
+        step_fn = step_fn or fa.attention_block_general
         state_factory = state_factory or fa.BlockState
 
     world = dist.get_world_size(group)

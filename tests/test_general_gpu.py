@@ -479,3 +479,25 @@ def test_causal_zigzag_ring_on_one_gpu(fa, oracle, dev):
         O[:, :, lo * Lc:(lo + 1) * Lc] = out[0].cpu().numpy()
         O[:, :, hi * Lc:(hi + 1) * Lc] = out[1].cpu().numpy()
     gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, "zig-zag ring on one GPU")
+
+
+def test_ring_forward_default_step_takes_any_length(fa, dev, tmp_path):
+    """multi_gpu.ring_forward with its default step (fa_forward_block_general) on one rank: rows per rank that are
+    not a multiple of 64 go through, and the result is that of the one-call entry point."""
+    import sys
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, fa.__path__[0])
+    import multi_gpu as mg
+
+    sys.modules.setdefault("flash_attention_amd", fa)
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rendezvous", rank=0, world_size=1)
+    try:
+        Q, K, V = normal_fp16(33, (1, 4, 700, 128))
+        q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+        out = mg.ring_forward(q, k, v)
+        torch.cuda.synchronize()
+        assert torch.equal(out, fa.attention_general(q, k, v))
+    finally:
+        dist.destroy_process_group()
