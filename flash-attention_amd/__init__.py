@@ -40,6 +40,10 @@ EXPORTED_SYMBOLS = (
     "fa_kernel_name",
     "fa_kernel_name_general",
     "fa_kernel_name_block_general",
+    "fa_split_ways",
+    "fa_set_reserved_cus",
+    "fa_get_reserved_cus",
+    "fa_debug_reload_env",
 )
 
 _lib = None
@@ -53,60 +57,73 @@ def lib() -> ct.CDLL:
     """Load the HIP library; fail loudly if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FlashAttentionError(
-                f"{LIB_PATH} not found: build it with flash-attention_amd/csrc/shared_compile.sh "
-                "(there is no CPU fallback)"
-            )
-        # PyTorch ships a HIP runtime of its own (same SONAME as /opt/rocm's).  Two HIP runtimes in
-        # one process do not work, so when torch is installed its copy must be mapped first; the
-        # dynamic linker then binds this library to that copy as well.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        L = ct.CDLL(LIB_PATH)
-        sig = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 5 + [ct.c_void_p, FloatPtr]
-        for name in ("run_tensor_flash_attention", "run_tensor_flash_attention_host_half"):
-            getattr(L, name).argtypes = sig
-            getattr(L, name).restype = None
-        for name in ("fa_forward", "fa_forward_host_half"):
-            getattr(L, name).argtypes = sig
-            getattr(L, name).restype = ct.c_int
-        L.fa_forward_block.argtypes = (
-            [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 6 + [ct.c_void_p]
-        )
-        L.fa_forward_block.restype = ct.c_int
-        L.fa_forward_general.argtypes = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
-        L.fa_forward_general.restype = ct.c_int
-        L.fa_forward_block_general.argtypes = (
-            [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 9 + [ct.c_void_p]
-        )
-        L.fa_forward_block_general.restype = ct.c_int
-        L.fa_forward_general_host_half.argtypes = L.fa_forward_general.argtypes
-        L.fa_forward_general_host_half.restype = ct.c_int
-        # the sibling libraries' symbols, with the argtypes the reference's caller declares
-        # (benchmarks/compare_impls.py:42-58)
-        L.run_naive_attention_host_half.argtypes = [HalfPtr] * 4 + [ct.c_int] * 5 + [ct.c_void_p, FloatPtr]
-        L.run_naive_attention_host_half.restype = None
-        L.run_cuda_cores_flash_attention_host_half.argtypes = [HalfPtr] * 4 + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
-        L.run_cuda_cores_flash_attention_host_half.restype = None
-        L.fa_init_half.argtypes = [HalfPtr, ct.c_size_t, ct.c_ulonglong, ct.c_void_p]
-        L.fa_init_half.restype = ct.c_int
-        L.fa_device_info.argtypes = [ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_double)]
-        L.fa_device_info.restype = ct.c_int
-        L.fa_last_error.argtypes = []
-        L.fa_last_error.restype = ct.c_char_p
-        L.fa_version.argtypes = []
-        L.fa_version.restype = ct.c_char_p
-        L.fa_kernel_name.argtypes = [ct.c_int, ct.c_int]
-        L.fa_kernel_name.restype = ct.c_char_p
-        L.fa_kernel_name_general.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int]
-        L.fa_kernel_name_general.restype = ct.c_char_p
-        L.fa_kernel_name_block_general.argtypes = [ct.c_int] * 6
-        L.fa_kernel_name_block_general.restype = ct.c_char_p
-        _lib = L
+        _lib = bind(LIB_PATH)
     return _lib
+
+
+def bind(path: str) -> ct.CDLL:
+    """dlopen a build of the library and declare its entry points' argument types."""
+    if not os.path.exists(path):
+        raise FlashAttentionError(
+            f"{path} not found: build it with flash-attention_amd/csrc/shared_compile.sh "
+            "(there is no CPU fallback)"
+        )
+    # PyTorch ships a HIP runtime of its own (same SONAME as /opt/rocm's).  Two HIP runtimes in
+    # one process do not work, so when torch is installed its copy must be mapped first; the
+    # dynamic linker then binds this library to that copy as well.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = ct.CDLL(path)
+    sig = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 5 + [ct.c_void_p, FloatPtr]
+    for name in ("run_tensor_flash_attention", "run_tensor_flash_attention_host_half"):
+        getattr(L, name).argtypes = sig
+        getattr(L, name).restype = None
+    for name in ("fa_forward", "fa_forward_host_half"):
+        getattr(L, name).argtypes = sig
+        getattr(L, name).restype = ct.c_int
+    L.fa_forward_block.argtypes = (
+        [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 6 + [ct.c_void_p]
+    )
+    L.fa_forward_block.restype = ct.c_int
+    L.fa_forward_general.argtypes = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
+    L.fa_forward_general.restype = ct.c_int
+    L.fa_forward_block_general.argtypes = (
+        [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 9 + [ct.c_void_p]
+    )
+    L.fa_forward_block_general.restype = ct.c_int
+    L.fa_forward_general_host_half.argtypes = L.fa_forward_general.argtypes
+    L.fa_forward_general_host_half.restype = ct.c_int
+    # the sibling libraries' symbols, with the argtypes the reference's caller declares
+    # (benchmarks/compare_impls.py:42-58)
+    L.run_naive_attention_host_half.argtypes = [HalfPtr] * 4 + [ct.c_int] * 5 + [ct.c_void_p, FloatPtr]
+    L.run_naive_attention_host_half.restype = None
+    L.run_cuda_cores_flash_attention_host_half.argtypes = [HalfPtr] * 4 + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
+    L.run_cuda_cores_flash_attention_host_half.restype = None
+    L.fa_init_half.argtypes = [HalfPtr, ct.c_size_t, ct.c_ulonglong, ct.c_void_p]
+    L.fa_init_half.restype = ct.c_int
+    L.fa_device_info.argtypes = [ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_double)]
+    L.fa_device_info.restype = ct.c_int
+    L.fa_last_error.argtypes = []
+    L.fa_last_error.restype = ct.c_char_p
+    L.fa_version.argtypes = []
+    L.fa_version.restype = ct.c_char_p
+    L.fa_kernel_name.argtypes = [ct.c_int, ct.c_int]
+    L.fa_kernel_name.restype = ct.c_char_p
+    L.fa_kernel_name_general.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int]
+    L.fa_kernel_name_general.restype = ct.c_char_p
+    L.fa_kernel_name_block_general.argtypes = [ct.c_int] * 6
+    L.fa_kernel_name_block_general.restype = ct.c_char_p
+    L.fa_split_ways.argtypes = [ct.c_int] * 3
+    L.fa_split_ways.restype = ct.c_int
+    L.fa_set_reserved_cus.argtypes = [ct.c_int]
+    L.fa_set_reserved_cus.restype = ct.c_int
+    L.fa_get_reserved_cus.argtypes = []
+    L.fa_get_reserved_cus.restype = ct.c_int
+    L.fa_debug_reload_env.argtypes = []
+    L.fa_debug_reload_env.restype = None
+    return L
 
 
 def _check(rc: int) -> None:
@@ -310,6 +327,17 @@ def init_half(t, seed: int, stream=None) -> None:
         stream = torch.cuda.current_stream(t.device)
     with torch.cuda.device(t.device):
         _check(lib().fa_init_half(_dev_half_ptr(t), t.numel(), seed, _stream_handle(stream)))
+
+
+def set_reserved_cus(k: int) -> None:
+    """``fa_set_reserved_cus``: persistent launches leave ``k`` compute units free for other streams' kernels
+    (the transport kernels of a ring's send/recv); 0 restores one workgroup per unit."""
+    _check(lib().fa_set_reserved_cus(int(k)))
+
+
+def reload_env() -> None:
+    """Re-read the FA_* environment switches (they are otherwise read once per process).  For tests and A/B runs."""
+    lib().fa_debug_reload_env()
 
 
 def device_info() -> dict:

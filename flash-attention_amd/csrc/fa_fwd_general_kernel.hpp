@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
         return;
     }
     // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r
-    const float inv = 1.0f / half_wave_sum(l_run);
+    const float l_tot = half_wave_sum(l_run);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;  // a row that has seen no key (every score masked): O = 0
     if (row_valid) {
         half_t* og = p.o + srow * D;
 #pragma unroll

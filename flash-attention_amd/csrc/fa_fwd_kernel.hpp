@@ -67,6 +67,7 @@ struct FwdParams {
     int flags;
     unsigned long long* stamps;  // diagnostic builds only (FA_STAMPS): 32 time stamps per workgroup
     int q_pos0, k_pos0;  // absolute position of query row 0 / key row 0 (causal mask of fa_fwd_general_kernel only)
+    int k_splits, lk_split, bh_real;  // fa_fwd_w64_split_kernel only: key ranges per head, keys per range, real heads
 };
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second.
@@ -309,7 +310,8 @@ __device__ __forceinline__ void finish_rows(const FwdParams& p, size_t srow, int
                 *reinterpret_cast<f32x4*>(oa + 32 * db + 8 * g4 + 4 * hh) = t;
             }
     } else {
-        const float inv = 1.0f / half_wave_sum(l_run);
+        const float l_tot = half_wave_sum(l_run);
+        const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;  // a row that has seen no key: O = 0, not 0/0
         half_t* og = p.o + srow * kHeadDim;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -365,7 +367,8 @@ __device__ __forceinline__ int opaque(int x) {
 // Rows below first_row (of the 32) are not stored.
 __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
                                                   float l_run, int first_row = 0) {
-    const float inv = 1.0f / half_wave_sum(l_run);
+    const float l_tot = half_wave_sum(l_run);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;  // a row that has seen no key: O = 0, not 0/0
     lane = opaque(lane);
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll

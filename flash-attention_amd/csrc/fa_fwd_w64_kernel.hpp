@@ -530,8 +530,15 @@ __device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int thr, int
 // A tile the diagonal touches or the ragged last tile gets mask_scores() in a cold branch between two phases.
 // (Four instantiations rather than run-time flags: the kernel has no scalar registers to spare; with both
 // features behind run-time flags the compiler kept scalars in vector lanes inside the tile loop, 7 % slower.)
-template <bool CAUSAL, bool RAGGED>
+//   SPLIT (whole tiles, no mask) divides every head's keys into p.k_splits equal ranges of p.lk_split keys and
+//     makes each (range, head) pair a head of its own: p.bh counts those, virtual head vh = range * p.bh_real +
+//     head reads Q of `head`, keys [range * lk_split, (range + 1) * lk_split) of `head`, and hands its
+//     un-normalised state to row vh * lq + i of (o_acc, row_max, row_sum) (the launcher sets kFlagStoreState and
+//     points them at a workspace; fa_split_merge_kernel folds the ranges).  For launches with fewer items than
+//     compute units.
+template <bool CAUSAL, bool RAGGED, bool SPLIT = false>
 __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
+    static_assert(!SPLIT || (!CAUSAL && !RAGGED), "the key split is built for whole tiles without a mask");
     constexpr bool MASKED = CAUSAL || RAGGED;
     constexpr int NWAVES = 4;
     constexpr int QB = 256;                        // query rows per item
@@ -569,7 +576,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     for (int i = 0; i < 4; ++i) w.v_ad[i] = v_lds + (unsigned)g.v_rd[i];
 
     const int n_items = p.bh * p.q_blocks;
-    const int n_tiles_all = RAGGED ? (p.lk + kKvTile - 1) / kKvTile : p.lk / kKvTile;  // >= 3
+    const int n_tiles_all = SPLIT ? p.lk_split / kKvTile : RAGGED ? (p.lk + kKvTile - 1) / kKvTile : p.lk / kKvTile;  // >= 3
     constexpr bool causal = CAUSAL;
     [[maybe_unused]] const int dup = RAGGED ? n_tiles_all * kKvTile - p.lk : 0;
     const int stride = (int)gridDim.x;
@@ -590,6 +597,15 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     };
     const float c = p.scale_log2e;
     constexpr size_t kTileElems = (size_t)kKvTile * kHeadDim;
+    // element offset of a head's first key row (SPLIT: of the virtual head's key range)
+    auto kv_base = [&](int hd) -> size_t {
+        if constexpr (SPLIT) {
+            const int range = hd / p.bh_real;
+            return ((size_t)(hd - range * p.bh_real) * p.lk + (size_t)range * p.lk_split) * kHeadDim;
+        } else {
+            return (size_t)hd * p.lk * kHeadDim;
+        }
+    };
 
     // ---- load cursor (an element offset common to K and V): the tile the next K transfer fetches.  It
     //      runs three tiles ahead of the compute stream; the V transfer of a step fetches the tile the
@@ -611,7 +627,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             int h_, q_;                                                                        \
             decode((cur_).item, h_, q_);                                                       \
             (cur_).nt = item_tiles(q_);                                                        \
-            (cur_).off = (size_t)h_ * p.lk * kHeadDim;                                         \
+            (cur_).off = kv_base(h_);                                                          \
         }                                                                                      \
     } while (0)
 #define W64_DMA_K(slot_)                                                                       \
@@ -652,11 +668,18 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         return r0;
     };
     auto source_row = [&](int hd, int blk) -> size_t { return (size_t)hd * p.lq + (size_t)row_pos(blk); };
+    // where those rows' Q comes from: the same place, except that a virtual head (SPLIT) reads its real head's
+    auto q_row = [&](int hd, int blk) -> size_t {
+        if constexpr (SPLIT)
+            return (size_t)(hd % p.bh_real) * p.lq + (size_t)row_pos(blk);
+        else
+            return source_row(hd, blk);
+    };
     auto owns_rows = [&](int blk) -> bool { return blk * QB + wave * 64 < p.lq; };
     // rows at the head of the wave's 64 that another wave owns (RAGGED, last rows of the sequence)
     [[maybe_unused]] auto rows_skipped = [&](int blk) -> int { return blk * QB + wave * 64 - row_pos(blk); };
-    size_t wrow = source_row(head, qb);  // this wave's first query row
-    Cursor kc = {item, 0, n_tiles, (size_t)head * p.lk * kHeadDim};
+    size_t wrow = source_row(head, qb);  // this wave's first query row (where its output or state goes)
+    Cursor kc = {item, 0, n_tiles, kv_base(head)};
     // Causal mask: `lim` is the position of the wave's first query row (in keys); a tile whose last key
     // lies beyond a sub-block's first row takes the mask (mask_scores, between the phases).
     [[maybe_unused]] int lim = row_pos(qb);
@@ -684,9 +707,12 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     //        Q_B rows, K(1), V(0)      | waited for before step 0 (behind S_A(0) and the state set-up)
     //        V(1), K(2)                | stay in flight: nothing reads them before step 1, and the wait at
     //                                    the end of step 0 covers them
-    dma_q_rows_asm(p.q + wrow * kHeadDim, img, lane);
-    W64_DMA_K(0);
-    dma_q_rows_asm(p.q + (wrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
+    {
+        const size_t qsrc = q_row(head, qb);
+        dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
+        W64_DMA_K(0);
+        dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
+    }
     const size_t off0 = kc.off;
     W64_ADVANCE(kc);
     W64_DMA_K(1);
@@ -819,8 +845,9 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             decode(next_item, nhead, nqb);
             nwrow = source_row(nhead, nqb);
             if (t + 2 == n_tiles) {
-                dma_q_rows_asm(p.q + nwrow * kHeadDim, img, lane);
-                dma_q_rows_asm(p.q + (nwrow + 32) * kHeadDim, img + 32 * kRowBytes, lane);
+                const size_t qsrc = q_row(nhead, nqb);
+                dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
+                dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
             }
         }
 
@@ -918,6 +945,38 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_causal_kernel(const FwdPara
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_kernel(const FwdParams p) { fa_fwd_w64_body<false, true>(p); }
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_causal_kernel(const FwdParams p) {
     fa_fwd_w64_body<true, true>(p);
+}
+// Whole tiles, no mask, every head's keys split into ranges (see SPLIT above).
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_split_kernel(const FwdParams p) {
+    fa_fwd_w64_body<false, false, true>(p);
+}
+
+// Folds the key ranges of fa_fwd_w64_split_kernel: row i of the output is
+//   O[i] = sum_s w_s o_s[i] / sum_s w_s l_s[i],   w_s = exp(m_s[i] - max_s m_s[i]),
+// the online-softmax merge of testing.cu:91-96 applied across ranges (o_s, m_s, l_s: row s * rows + i of the
+// state arrays, m in natural-log units as the blockwise entry points keep it).  Half a wave per row: lane c holds
+// columns 4c .. 4c+3.  A range that saw no key (l = 0) contributes nothing.
+__global__ __launch_bounds__(256) void fa_split_merge_kernel(const float* __restrict__ o_acc, const float* __restrict__ row_max,
+                                                             const float* __restrict__ row_sum, half_t* __restrict__ o,
+                                                             size_t rows, int n_ranges) {
+    const int c = threadIdx.x & 31;
+    const size_t per_pass = (size_t)gridDim.x * 8;
+    for (size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5); i < rows; i += per_pass) {
+        float m = -__builtin_inff();
+        for (int s = 0; s < n_ranges; ++s) m = fmaxf(m, row_max[(size_t)s * rows + i]);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        float l = 0.0f;
+        for (int s = 0; s < n_ranges; ++s) {
+            const size_t r = (size_t)s * rows + i;
+            const float w = __expf(row_max[r] - m);
+            l += w * row_sum[r];
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(o_acc + r * kHeadDim) + c);
+            acc += t * w;
+        }
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        const half4 h = __builtin_convertvector(acc * inv, half4);
+        __builtin_nontemporal_store(h, reinterpret_cast<half4*>(o + i * kHeadDim) + c);
+    }
 }
 
 #undef W64_ADVANCE

@@ -6,10 +6,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -37,50 +39,92 @@ int fail(int code, const char* fmt, const char* detail = "") {
         }                                                                                 \
     } while (0)
 
+// Environment switches (A/B comparisons and tests; a production caller sets none of them).  They are read
+// ONCE per process, on the first call that needs them: a launch costs no getenv, and concurrent callers
+// see one consistent snapshot.  fa_debug_reload_env() takes a new snapshot (for tests that change them).
+//   FA_W64=1 / 0         the one-wave-per-SIMD kernel from three K/V tiles per item on / never (default: from five)
+//   FA_PERSISTENT=0      one workgroup per item instead of one per compute unit
+//   FA_MASKED_W64=1 / 0  masked forms of that kernel wherever they can run / nowhere (default: where measured faster)
+//   FA_BLOCK_TUNED=0     fa_forward_block_general keeps every block on the general kernel
+//   FA_SPLIT=0 / n       never split an item's keys over workgroups / over n of them (default: by the cost model)
+//   FA_RESERVED_CUS=k    initial value of fa_set_reserved_cus()
+//   FA_NWAVES=4, FA_RING=0   (builds with -DFA_AB_KERNELS only) the register-staged kernels kept for comparisons
+struct Switches {
+    int nwaves = 8;
+    int w64_from = 5 * fa::kKvTile;
+    bool ring = true;
+    bool persistent = true;
+    int masked_w64 = -1;  // -1: the library's own choice
+    bool block_tuned = true;
+    int split = -1;  // -1: the cost model's choice
+};
+std::atomic<const Switches*> g_switches{nullptr};
+std::once_flag g_switches_once;
+std::atomic<int> g_reserved_cus{0};
+
+const Switches* read_switches() {
+    auto* sw = new Switches();
+    auto geti = [](const char* name, int& out) {
+        const char* e = std::getenv(name);
+        if (e) out = std::atoi(e);
+        return e != nullptr;
+    };
+    int x = 0;
+#ifdef FA_AB_KERNELS
+    if (geti("FA_NWAVES", x) && (x == 4 || x == 8)) sw->nwaves = x;
+    if (geti("FA_RING", x)) sw->ring = x != 0;
+#endif
+    if (geti("FA_W64", x)) sw->w64_from = x != 0 ? 3 * fa::kKvTile : 0x7fffffff;
+    if (geti("FA_PERSISTENT", x)) sw->persistent = x != 0;
+    if (geti("FA_MASKED_W64", x)) sw->masked_w64 = x != 0;
+    if (geti("FA_BLOCK_TUNED", x)) sw->block_tuned = x != 0;
+    if (geti("FA_SPLIT", x) && x >= 0) sw->split = x;
+    if (geti("FA_RESERVED_CUS", x) && x >= 0) g_reserved_cus.store(x, std::memory_order_relaxed);
+    return sw;
+}
+const Switches& switches() {
+    std::call_once(g_switches_once, [] { g_switches.store(read_switches(), std::memory_order_release); });
+    return *g_switches.load(std::memory_order_acquire);
+}
+
 // Workgroup shape: 256 query rows per workgroup, one workgroup per CU.  A last block of fewer than 256
 // rows leaves some waves without rows of their own (they compute along and store nothing); measured
-// on every L % 64 == 0 from 64 up this still beats 128-row workgroups.  FA_NWAVES=4 selects the 4-wave
-// register-staged kernel for A/B comparisons.
-int pick_waves(int bh, int lq, int lk) {
-    (void)bh;
-    (void)lq;
-    (void)lk;
-    if (const char* e = std::getenv("FA_NWAVES")) {
-        const int n = std::atoi(e);
-        if (n == 4 || n == 8) return n;
-    }
-    return 8;
-}
+// on every L % 64 == 0 from 64 up this still beats 128-row workgroups.  (FA_NWAVES=4 in an A/B build selects
+// the 4-wave register-staged kernel.)
+int pick_waves() { return switches().nwaves; }
 
 // Which kernel serves a shape.  The one-wave-per-SIMD kernel needs three K/V tiles per item for its
 // pipeline and wins from five on (measured: L = 192 and 256 run 3-8 % faster on the 8-wave ring kernel,
-// L = 320 and up faster here).  FA_W64=1 forces it from three tiles on, FA_W64=0 / FA_RING=0 step down
-// to the older kernels for A/B comparisons.
+// L = 320 and up faster here).
 enum KernelId { kKernelW64, kKernelRing, kKernelStaged8, kKernelStaged4 };
 const char* const kKernelNames[] = {"fa::fa_fwd_w64_kernel", "fa::fa_fwd_ring_kernel<8>", "fa::fa_fwd_kernel<8>",
                                     "fa::fa_fwd_kernel<4>"};
 KernelId pick_kernel(int nw, int lq, int lk) {
     (void)lq;
+    const Switches& sw = switches();
     if (nw != 8) return kKernelStaged4;
-    int w64_from = 5 * fa::kKvTile;
-    bool ring = true;
-    if (const char* e = std::getenv("FA_W64")) w64_from = std::atoi(e) != 0 ? 3 * fa::kKvTile : 0x7fffffff;
-    if (const char* e = std::getenv("FA_RING")) ring = std::atoi(e) != 0;
-    if (lk >= w64_from) return kKernelW64;
-    return ring ? kKernelRing : kKernelStaged8;
+    if (lk >= sw.w64_from) return kKernelW64;
+    return sw.ring ? kKernelRing : kKernelStaged8;
 }
 
-// Compute units of the current device (cached per device id).
+// Compute units of the current device (cached per device id; racing first calls store the same value).
 int device_cus() {
-    static int cached[64] = {0};
+    static std::atomic<int> cached[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int cus = 0;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached[dev] = cus;
+        cached[dev].store(cus, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return cus;
+}
+// Resident workgroups of a persistent launch: one per compute unit, less the units a caller has asked to be
+// left free for other streams' kernels (fa_set_reserved_cus).
+long persistent_grid() {
+    const int cus = device_cus();
+    const int k = g_reserved_cus.load(std::memory_order_relaxed);
+    return (long)(k < cus ? cus - k : 1);
 }
 
 #ifdef FA_STAMPS
@@ -88,34 +132,124 @@ unsigned long long* g_stamps = nullptr;
 extern "C" void fa_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
 #endif
 
-int launch(const fa::FwdParams& base, hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------
+// Key split.  A launch with fewer (head, 256-row block) items than compute units leaves units idle: B = 1,
+// H = 2, L = 16384 (one rank's share of 16 heads on 8 GPUs) is 128 items for 256 units.  Such launches divide
+// every head's keys into S equal ranges, run fa_fwd_w64_split_kernel on the S * B * H virtual heads (each writes
+// its un-normalised state into a workspace) and fold the ranges with fa_split_merge_kernel.
+//
+// Workspace per virtual row: 128 fp32 of accumulator + row max + row sum = 520 bytes, laid out as three arrays
+// [S * BH * Lq][128], [S * BH * Lq], [S * BH * Lq] (the first one first: it needs 16-byte alignment).
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kSplitRowBytes = (size_t)fa::kHeadDim * sizeof(float) + 2 * sizeof(float);
+constexpr size_t kSplitMaxRows = 262144;  // virtual rows a split launch may take (136 MB of workspace)
+
+// S for a launch of bh heads, q_blocks 256-row blocks per head and lk keys on `grid` resident workgroups;
+// 1 = no split.  Cost model in microseconds: a workgroup takes about 1.3 us per 64-key tile; a split adds a
+// second launch and the workspace traffic (written once, read once) at about 3 TB/s.  A range must keep eight
+// tiles, so that the pipeline's fill and drain stay small beside it.
+int pick_split(int bh, int q_blocks, int lq, int lk, long grid, size_t max_rows) {
+    const Switches& sw = switches();
+    const long items = (long)bh * q_blocks;
+    const int tiles = lk / fa::kKvTile;
+    auto valid = [&](int S) {
+        return S >= 2 && tiles % S == 0 && tiles / S >= 3 && (size_t)S * bh * lq <= max_rows &&
+               (long)S * bh <= 0x7fffffffL / 64;
+    };
+    if (sw.split == 0 || lk % fa::kKvTile != 0) return 1;
+    if (sw.split > 0) return valid(sw.split) ? sw.split : 1;
+    if (items >= 2 * grid) return 1;
+    auto rounds = [&](long n) { return (double)((n + grid - 1) / grid); };
+    const double t_tile = 1.3, t_launch = 10.0, bytes_per_us = 3.0e6;
+    double best = rounds(items) * tiles * t_tile;
+    int best_s = 1;
+    for (int S = 2; S <= 32; ++S) {
+        if (!valid(S) || tiles / S < 8) continue;
+        const double t = rounds(items * S) * (tiles / S) * t_tile + t_launch +
+                         2.0 * (double)S * bh * lq * (double)kSplitRowBytes / bytes_per_us;
+        if (t < 0.95 * best) {
+            best = t;
+            best_s = S;
+        }
+    }
+    return best_s;
+}
+
+// The split launch itself: `ws` holds kSplitRowBytes * S * bh * lq bytes (256-byte aligned).
+int launch_split(const fa::FwdParams& base, int S, void* ws, hipStream_t stream) {
+    fa::FwdParams p = base;
+    const size_t rows = (size_t)base.bh * base.lq, vrows = rows * S;
+    p.q_blocks = (p.lq + 255) / 256;
+    p.bh_real = base.bh;
+    p.bh = base.bh * S;
+    p.k_splits = S;
+    p.lk_split = base.lk / S;
+    p.o_acc = static_cast<float*>(ws);
+    p.row_max = p.o_acc + vrows * fa::kHeadDim;
+    p.row_sum = p.row_max + vrows;
+    p.flags = fa::kFlagStoreState;
+    const long items = (long)p.bh * p.q_blocks;
+    long grid = persistent_grid();
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(fa::fa_fwd_w64_split_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    FA_HIP(hipGetLastError());
+    long mgrid = (long)((rows + 7) / 8);
+    const long mmax = 8L * device_cus();
+    if (mgrid > mmax) mgrid = mmax;
+    hipLaunchKernelGGL(fa::fa_split_merge_kernel, dim3((unsigned)mgrid), dim3(256), 0, stream, p.o_acc, p.row_max,
+                       p.row_sum, base.o, rows, S);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+
+// Where a split launch may take its workspace from.
+enum class Workspace {
+    kNone,     // blockwise calls and callers without one: never split
+    kStream,   // allocate on the stream (hipMallocAsync / hipFreeAsync); no split if that fails
+};
+
+int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Workspace::kNone) {
     fa::FwdParams p = base;
 #ifdef FA_STAMPS
     p.stamps = g_stamps;
 #endif
-    const int nw = pick_waves(p.bh, p.lq, p.lk);
+    const int nw = pick_waves();
     const int qb_rows = nw * fa::kRowsPerWave;
     p.q_blocks = (p.lq + qb_rows - 1) / qb_rows;
     const long items = (long)p.bh * p.q_blocks;
     if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
-    // Resident workgroups: registers admit 8 waves per CU, i.e. one 8-wave or two 4-wave
-    // workgroups.  More items than that are walked by the resident workgroups as one stream.
-    long grid = (long)device_cus();  // LDS admits one workgroup per CU for either size
-    if (const char* e = std::getenv("FA_PERSISTENT"))
-        if (std::atoi(e) == 0) grid = items;
+    // Resident workgroups: registers and LDS admit one workgroup per CU.  More items than that are walked by
+    // the resident workgroups as one stream.
+    long grid = switches().persistent ? persistent_grid() : items;
+    const KernelId kid = pick_kernel(nw, p.lq, p.lk);
+    if (kid == kKernelW64 && wsk != Workspace::kNone && p.flags == 0 && switches().persistent) {
+        const int S = pick_split(p.bh, p.q_blocks, p.lq, p.lk, grid, kSplitMaxRows);
+        if (S > 1) {
+            const size_t bytes = (size_t)S * p.bh * p.lq * kSplitRowBytes;
+            void* ws = nullptr;
+            if (hipMallocAsync(&ws, bytes, stream) == hipSuccess && ws) {
+                const int rc = launch_split(p, S, ws, stream);
+                (void)hipFreeAsync(ws, stream);
+                return rc;
+            }
+            (void)hipGetLastError();  // no stream-ordered allocator: run unsplit
+        }
+    }
     if (grid > items) grid = items;
-    switch (pick_kernel(nw, p.lq, p.lk)) {
+    switch (kid) {
         case kKernelW64:
             hipLaunchKernelGGL(fa::fa_fwd_w64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
             break;
-        case kKernelRing:
-            hipLaunchKernelGGL(fa::fa_fwd_ring_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
-            break;
+#ifdef FA_AB_KERNELS
         case kKernelStaged8:
             hipLaunchKernelGGL(fa::fa_fwd_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
             break;
-        default:
+        case kKernelStaged4:
             hipLaunchKernelGGL(fa::fa_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+            break;
+#endif
+        default:
+            hipLaunchKernelGGL(fa::fa_fwd_ring_kernel<8>, dim3((unsigned)grid), dim3(512), 0, stream, p);
             break;
     }
     FA_HIP(hipGetLastError());
@@ -183,12 +317,12 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
 // (tools/bench_general.py --ragged-sweep --fine, B*L = 16384, H = 16): without the mask they win from
 // Lq = 512 on and below that with more than 128 rows in the last block; with the mask from Lq = 1088 on, from
 // 385 on with more than 128 rows in the last block, and at 192 and 256.  FA_MASKED_W64=1 takes them wherever
-// they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests).
+// they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests; see Switches).
 bool masked_on_w64(int flags, int D, int lq, int lk) {
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (D != fa::kHeadDim || lq < 64 || lk < 3 * fa::kKvTile || (causal && lq != lk)) return false;
     if (!causal && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return false;  // the unmasked kernels' shapes
-    if (const char* e = std::getenv("FA_MASKED_W64")) return std::atoi(e) != 0;
+    if (switches().masked_w64 >= 0) return switches().masked_w64 != 0;
     const int last_block_rows = (lq - 1) % 256 + 1;
     if (!causal) return lq >= 512 || last_block_rows > 128;
     return lq >= 1088 || (lq >= 385 && last_block_rows > 128) || lq == 192 || lq == 256;
@@ -205,7 +339,7 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
     p.q_blocks = (p.lq + 255) / 256;
     const long items = (long)p.bh * p.q_blocks;
     if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "masked kernel: grid size out of range%s");
-    long grid = (long)device_cus();
+    long grid = persistent_grid();
     if (grid > items) grid = items;
     const bool ragged = p.lq % fa::kKvTile != 0 || p.lk % fa::kKvTile != 0;
     const dim3 g((unsigned)grid), b(256);
@@ -230,8 +364,7 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
 enum BlockRoute { kRouteGeneral, kRouteTuned, kRouteMaskedW64, kRouteUnmaskedRaggedW64 };
 BlockRoute block_route(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     if (D != fa::kHeadDim) return kRouteGeneral;
-    if (const char* e = std::getenv("FA_BLOCK_TUNED"))
-        if (std::atoi(e) == 0) return kRouteGeneral;
+    if (!switches().block_tuned) return kRouteGeneral;
     const bool whole = lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0;
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (!causal || (long)k_pos0 + lk - 1 <= (long)q_pos0) {
@@ -313,8 +446,29 @@ extern "C" {
 
 const char* fa_last_error(void) { return g_last_error; }
 
-const char* fa_version(void) { return "flash_attention gfx950 0.1"; }
-const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(1, lq, lk), lq, lk)]; }
+const char* fa_version(void) { return "flash_attention gfx950 0.2"; }
+
+void fa_debug_reload_env(void) {
+    (void)switches();  // the first snapshot, if there was none
+    g_switches.store(read_switches(), std::memory_order_release);  // (the old snapshot is left alive: readers may hold it)
+}
+
+int fa_set_reserved_cus(int k) {
+    if (k < 0) return fail(FA_ERR_SHAPE, "fa_set_reserved_cus: k must not be negative%s");
+    (void)switches();  // so that a later first read of FA_RESERVED_CUS does not overwrite this value
+    g_reserved_cus.store(k, std::memory_order_relaxed);
+    return FA_OK;
+}
+int fa_get_reserved_cus(void) {
+    (void)switches();
+    return g_reserved_cus.load(std::memory_order_relaxed);
+}
+const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(), lq, lk)]; }
+int fa_split_ways(int bh, int lq, int lk) {
+    if (bh <= 0 || lq <= 0 || lk <= 0 || lq % fa::kKvTile != 0 || lk % fa::kKvTile != 0) return 1;
+    if (pick_kernel(pick_waves(), lq, lk) != kKernelW64 || !switches().persistent) return 1;
+    return pick_split(bh, (lq + 255) / 256, lq, lk, persistent_grid(), kSplitMaxRows);
+}
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
         case kRouteTuned: return fa_kernel_name(lq, lk);
@@ -355,7 +509,7 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
     p.lk = L;
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
     p.flags = 0;
-    return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream); });
+    return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream, Workspace::kStream); });
 }
 
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
@@ -379,7 +533,7 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     if (flags == 0 && D == fa::kHeadDim && Lq % fa::kKvTile == 0 && Lk % fa::kKvTile == 0) {
         // query and key lengths differ, both in whole tiles: the tuned kernels take that as well
         p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
-        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream); });
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream, Workspace::kStream); });
     }
     if (masked_on_w64(flags, D, Lq, Lk))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_masked(p, stream); });

@@ -75,8 +75,9 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
         step_fn = step_fn or fa.attention_block_general
         state_factory = state_factory or fa.BlockState
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    # (no process group: a single rank, which folds its own block and is done)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     B, H, Lq, D = q.shape
     state = state_factory(B * H, Lq, D, q.device)
     if world == 1:

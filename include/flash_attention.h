@@ -71,7 +71,15 @@ enum {
 };
 
 /* Same work and arguments as run_tensor_flash_attention, but returns a status
- * instead of throwing; the two drop-in functions are thin shells over these. */
+ * instead of throwing; the two drop-in functions are thin shells over these.
+ *
+ * Launches with fewer (head, 256-row query block) items than the device has compute units (few heads and a
+ * long sequence: B*H*ceil(L/256) < 256, e.g. one rank's two heads of B=1, H=16, L=16384 sharded over eight
+ * GPUs) divide every head's keys into ranges, run the ranges as heads of their own and fold them with a
+ * second, small kernel.  The reference never meets this: its grid is (L/64, B, H) workgroups of 64 rows
+ * (wrapper.cu:74-76).  The workspace (520 bytes per query row and range) is taken from the stream's memory pool
+ * (hipMallocAsync / hipFreeAsync: stream-ordered, no device synchronisation) and returned to it by the same call;
+ * other launches allocate nothing. */
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
                int D, int tile, void* stream, float* elapsed_ms);
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
@@ -87,7 +95,9 @@ int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t*
  *   row_sum       [BH][Lq] fp32 running sum of exp(score/sqrt(D)-row_max)
  *   first != 0    ignore the incoming state (start from zero)
  *   last  != 0    write dO = o_acc/row_sum as fp16 and leave the state untouched;
- *                 otherwise update o_acc,row_max,row_sum and leave dO untouched
+ *                 otherwise update o_acc,row_max,row_sum and leave dO untouched.
+ *                 A row that has seen no key at all by then (row_sum == 0: possible only through
+ *                 fa_forward_block_general's mask) gets O = 0.
  * Lq and Lk must be multiples of 64.  Asynchronous on `stream`. */
 int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
                      float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int first, int last,
@@ -113,7 +123,9 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
  * i of this block iff k_pos0 + j <= q_pos0 + i, the positions being those of the rows in the whole
  * sequence: the blocks of a causal sequence can then be folded in any order (a row that sees no key
  * of a block keeps its state), which the zig-zag sequence-parallel ring needs.  attention_cpu has
- * the mask for whole sequences only (testing.cu:74-77). */
+ * the mask for whole sequences only (testing.cu:74-77).  Setting `last` while some row has seen no key
+ * of any block (a block wholly above the diagonal folded alone, q_pos0 < k_pos0 on a first block) is
+ * accepted: those rows of dO are written as 0, never NaN. */
 int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
                              float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int flags, int q_pos0,
                              int k_pos0, int first, int last, void* stream);
@@ -149,6 +161,18 @@ int fa_init_half(uint16_t* dptr, size_t n, unsigned long long seed, void* stream
  * (v_mfma_f32_32x32x16_f16: 32768 FLOP per 32 cycles per SIMD). */
 int fa_device_info(int* compute_units, int* clock_khz, double* fp16_dense_peak_flops);
 
+/* Persistent launches (the D = 128 kernels: one resident workgroup per compute unit, each holding the unit's
+ * whole LDS) leave k compute units unused from the next call on, so that kernels of OTHER streams can become
+ * resident while an attention kernel runs: the transport kernels of a ring step's send/recv next to its
+ * compute.  Process-wide, 0 by default (initial value: environment variable FA_RESERVED_CUS).  No counterpart
+ * in the reference, which has no multi-device mode. */
+int fa_set_reserved_cus(int k);
+int fa_get_reserved_cus(void);
+
+/* The library reads its FA_* environment switches (kernel selection for A/B comparisons and tests) once per
+ * process; this takes a new snapshot.  For tests; not for concurrent use with launches. */
+void fa_debug_reload_env(void);
+
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* fa_last_error(void);
 
@@ -160,6 +184,10 @@ const char* fa_version(void);
  * counterpart in the reference, whose wrapper picks among seven instantiations of one kernel
  * (flash_attention_tensor_cores/wrapper.cu:89-185). */
 const char* fa_kernel_name(int lq, int lk);
+/* Into how many key ranges a call of fa_forward on B*H = bh heads of lq query rows and lk keys divides each head
+ * on the current device (1: no split; then fa_kernel_name names the only kernel, otherwise
+ * fa::fa_fwd_w64_split_kernel runs, followed by fa::fa_split_merge_kernel). */
+int fa_split_ways(int bh, int lq, int lk);
 /* The same for a call of fa_forward_general (flags as there). */
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags);
 /* The same for a call of fa_forward_block_general. */

@@ -26,6 +26,36 @@ def fa():
     return ge.load_package()
 
 
+SWITCHES = ("FA_W64", "FA_PERSISTENT", "FA_MASKED_W64", "FA_BLOCK_TUNED", "FA_SPLIT", "FA_RESERVED_CUS", "FA_NWAVES",
+            "FA_RING")
+
+
+@pytest.fixture
+def fa_env(fa):
+    """Set the library's environment switches for one test: ``fa_env(FA_W64="1", FA_SPLIT=None)`` (None = unset).
+    The library reads them once per process, so every change is followed by a reload; the test's end restores
+    the environment it found."""
+    saved = {k: os.environ.get(k) for k in SWITCHES}
+
+    def set_(**kv):
+        for k, v in kv.items():
+            assert k in SWITCHES, k
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        fa.reload_env()
+
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    fa.reload_env()
+    fa.set_reserved_cus(int(os.environ.get("FA_RESERVED_CUS", "0")))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle as o

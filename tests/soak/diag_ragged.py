@@ -18,6 +18,7 @@ q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
 outs = {}
 for name, env in (("masked", "1"), ("general", "0")):
     os.environ["FA_MASKED_W64"] = env
+    fa.reload_env()
     print(name, fa.lib().fa_kernel_name_general(L, L, 128, int(causal)).decode())
     outs[name] = fa.attention_general(q, k, v, causal=causal).float().cpu().numpy()
 ref = oracle.attention_cpu(Q, K, V, causal=causal)

@@ -42,6 +42,7 @@ def causal_mode():
     mg = import_module("multi_gpu")
     if args.general_only:
         os.environ["FA_BLOCK_TUNED"] = "0"
+        fa.reload_env()
     Lc = L // (2 * P)
     g = torch.Generator(device=dev).manual_seed(1)
     K, V, Qall = [torch.randn((1, H, L, D), generator=g, device=dev, dtype=torch.float32).to(torch.float16) for _ in range(3)]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_line():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--preheat-seconds", "0.2",
-           "--no-sweep", "--cpu-seconds", "1"]
+           "--no-sweep", "--cpu-seconds", "1"]  # (keeps normal_data_tflops / reference_protocol_tflops)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -34,6 +34,34 @@ def test_bench_json_line():
     assert rf["kernel"] == "fa::fa_fwd_w64_kernel" and rf["kernel_ms"] > 0
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert j["normal_data_tflops"] > 0 and j["reference_protocol_tflops"] > 0 and j["pct_of_fp16_peak"] > 0
+    assert j["per_rank_kernel_ms"] == [rf["kernel_ms"]] and rf["key_split_ways"] == 1
+
+
+def _bench(*argv, env=None, timeout=280):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + list(argv)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_shape_on_one_gpu():
+    """--scaling strong --seq-len 16384: B=1, H=16 (the heads would be split over the ranks; one rank holds all)."""
+    j = _bench("--seq-len", "16384", "--scaling", "strong", "--steps", "3", "--warmup", "1", "--preheat-seconds", "0.2",
+               "--no-sweep", "--no-cpu-baseline", "--no-extras")
+    assert j["scaling"] == "strong" and j["n_gpus"] == 1 and j["config"]["per_gpu_heads"] == 16
+    assert "L=16384" in j["config"]["workload"] and j["roofline"]["bound"] == "mfma"
+    assert abs(j["value"] - 4 * 16 * 16384 * 16384 * 128 / (j["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * j["value"]
+
+
+def test_bench_ring_mode_on_one_gpu():
+    """--ring on one rank: the whole sequence is one block; the line carries the ring's timing fields."""
+    j = _bench("--ring", "--seq-len", "8192", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert j["scaling"] == "strong" and j["n_gpus"] == 1 and "ring" in j["config"]["workload"]
+    assert j["ring"]["steps_per_pass"] == 1 and j["ring"]["exchange_only_ms_per_ring_step"] is None
+    assert j["ring"]["compute_only_ms_per_ring_step"] > 0 and j["value"] > 0
 
 
 def test_bench_multi_rank_code_path_with_one_rank():
@@ -47,7 +75,7 @@ def test_bench_multi_rank_code_path_with_one_rank():
     env = dict(os.environ, FA_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
-           "--preheat-seconds", "0.3", "--no-sweep", "--no-cpu-baseline"]
+           "--preheat-seconds", "0.3", "--no-sweep", "--no-cpu-baseline", "--no-extras"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

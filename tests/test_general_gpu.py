@@ -110,13 +110,13 @@ def masked_tuned(Lq, Lk, causal):
     return b"fa::fa_fwd_w64_ragged_kernel"
 
 
-def test_masked_kernel_choice(fa, monkeypatch):
+def test_masked_kernel_choice(fa, fa_env):
     """D = 128 with the causal mask or ragged lengths: the masked forms of the one-wave-per-SIMD kernel where they
     were measured faster than the general kernel (long sequences, or a last 256-row block more than half full);
     FA_MASKED_W64=1 extends them to every shape they can run (Lq >= 64, three tiles of keys)."""
     name = fa.lib().fa_kernel_name_general
     general = b"fa::fa_fwd_general_kernel<128>"
-    monkeypatch.delenv("FA_MASKED_W64", raising=False)
+    fa_env(FA_MASKED_W64=None)
     for L in (192, 256, 448, 500, 512, 700, 1088, 16383, 16384):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
     for L in (64, 128, 193, 320, 384, 576, 640, 1025):
@@ -127,22 +127,22 @@ def test_masked_kernel_choice(fa, monkeypatch):
         assert name(Lq, Lk, 128, 0) == general
     assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>" and name(511, 511, 256, 0).endswith(b"<256>")
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
-    monkeypatch.setenv("FA_MASKED_W64", "1")
+    fa_env(FA_MASKED_W64="1")
     for L in (320, 200, 577):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
     assert name(64, 193, 128, 0) == masked_tuned(64, 193, False)
     assert name(128, 128, 128, 1) == general and name(63, 500, 128, 0) == general and name(100, 191, 128, 0) == general
-    monkeypatch.setenv("FA_MASKED_W64", "0")
+    fa_env(FA_MASKED_W64="0")
     assert name(512, 512, 128, 1) == general and name(511, 511, 128, 0) == general
 
 
 @pytest.mark.parametrize("B,H,L", [(2, 2, 192), (1, 3, 256), (2, 3, 320), (1, 5, 448), (2, 4, 512), (1, 3, 576),
                                    (1, 2, 1024), (1, 3, 1088)])
-def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L, monkeypatch):
+def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L, fa_env):
     """Whole tensors against attention_cpu(causal); the shortest sequence the kernel takes (three tiles) and
     lengths with a partly filled last query block included (320, 448, 576, 1088: waves without rows of their
     own)."""
-    monkeypatch.setenv("FA_MASKED_W64", "1")
+    fa_env(FA_MASKED_W64="1")
     assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == CAUSAL_TUNED
     Q, K, V = normal_fp16(300 + L, (B, H, L, 128))
     O = run_general(fa, dev, Q, K, V, causal=True)
@@ -151,7 +151,7 @@ def test_causal_mask_on_the_tuned_kernel(fa, oracle, dev, B, H, L, monkeypatch):
 
 
 @pytest.mark.parametrize("B,H,L", [(8, 16, 1024), (7, 21, 512), (5, 16, 2560), (3, 5, 1280)])
-def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, monkeypatch):
+def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, fa_env):
     """More items than workgroups: two whole rounds (the second dealt in reverse), a partial second round with
     B*H not a multiple of 8, two whole rounds plus a partial one, and fewer items than workgroups.  Every row of
     every head against the general kernel (a head or block computed twice, not at all or with another block's
@@ -163,7 +163,7 @@ def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, monkeypatch):
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
     o = torch.full_like(q, float("nan"))
     fa.attention_general(q, k, v, causal=True, out=o)
-    monkeypatch.setenv("FA_MASKED_W64", "0")
+    fa_env(FA_MASKED_W64="0")
     assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
     o_ref = fa.attention_general(q, k, v, causal=True)
     torch.cuda.synchronize()
@@ -178,11 +178,11 @@ def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, monkeypatch):
                                           (513, 513, False), (300, 1000, False), (777, 640, False), (640, 777, False),
                                           (255, 255, True), (257, 257, True), (200, 200, True), (511, 511, True),
                                           (513, 513, True), (1000, 1000, True), (1087, 1087, True)])
-def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, monkeypatch):
+def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, fa_env):
     """Lengths that are not whole tiles on the masked kernel: the last key tile is read shifted down to the last
     key (its repeated rows masked), a wave whose rows would pass the last query row takes the last 64 rows and
     stores only its own.  NaN-padded inputs and a sentinel-padded output catch reads and writes past the end."""
-    monkeypatch.setenv("FA_MASKED_W64", "1")
+    fa_env(FA_MASKED_W64="1")
     assert fa.lib().fa_kernel_name_general(Lq, Lk, 128, int(causal)) == masked_tuned(Lq, Lk, causal)
     rng = np.random.default_rng(Lq * 7 + Lk)
     B, H = 2, 3
@@ -202,18 +202,18 @@ def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, mon
 
 
 @pytest.mark.parametrize("B,H,L,causal", [(9, 16, 1000, False), (7, 21, 705, True), (4, 16, 2100, True)])
-def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, monkeypatch):
+def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, fa_env):
     """Several items per workgroup with ragged lengths: every row against the general kernel, sampled rows
     against the oracle."""
     import torch
 
-    monkeypatch.delenv("FA_MASKED_W64", raising=False)
+    fa_env(FA_MASKED_W64=None)
     assert fa.lib().fa_kernel_name_general(L, L, 128, int(causal)) == masked_tuned(L, L, causal)
     Q, K, V = normal_fp16(500 + L, (B, H, L, 128))
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
     o = torch.full_like(q, float("nan"))
     fa.attention_general(q, k, v, causal=causal, out=o)
-    monkeypatch.setenv("FA_MASKED_W64", "0")
+    fa_env(FA_MASKED_W64="0")
     o_ref = fa.attention_general(q, k, v, causal=causal)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(o.float()).all())
@@ -335,15 +335,15 @@ def test_blockwise_general_blocks_in_any_order(fa, oracle, dev, D):
     gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), out.cpu().numpy(), f"any order D={D}")
 
 
-def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, dev, monkeypatch):
+def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, dev, fa_env):
     """fa_forward_block_general sends a block to the tuned kernels when it needs no mask and has their shape, and
     the diagonal block of a causal sequence to the causal tuned kernel; the kernels carry the same state, so a
     sequence may mix them: three chunks of 512 rows and a ragged tail of 100, each query chunk folded over its
     key chunks in shuffled order, against attention_cpu(causal) over the whole sequence."""
     import torch
 
-    monkeypatch.delenv("FA_MASKED_W64", raising=False)
-    monkeypatch.delenv("FA_BLOCK_TUNED", raising=False)
+    fa_env(FA_MASKED_W64=None)
+    fa_env(FA_BLOCK_TUNED=None)
     name = fa.lib().fa_kernel_name_block_general
     general, tuned = b"fa::fa_fwd_general_kernel<128>", b"fa::fa_fwd_w64_kernel"
     assert name(512, 512, 128, 1, 512, 512) == CAUSAL_TUNED     # the diagonal block
@@ -375,7 +375,7 @@ def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, d
     gate(oracle, ref, out.cpu().numpy(), "mixed kernels, blockwise causal")
 
     # the same sequence with everything on the general kernel: same gate (and close to the mixed run)
-    monkeypatch.setenv("FA_BLOCK_TUNED", "0")
+    fa_env(FA_BLOCK_TUNED="0")
     assert name(512, 512, 128, 1, 512, 512) == general
     st = fa.BlockState(B * H, L, 128, dev)
     out_g = fa.attention_block_general(q, k, v, st, last=True, causal=True)
@@ -384,13 +384,13 @@ def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, d
     assert float((out.float() - out_g.float()).abs().max()) <= 1e-3
 
 
-def test_blockwise_general_ragged_chunks_on_the_tuned_kernels(fa, oracle, dev, monkeypatch):
+def test_blockwise_general_ragged_chunks_on_the_tuned_kernels(fa, oracle, dev, fa_env):
     """Chunks that are not whole tiles: unmasked pairs on the ragged form of the tuned kernel, diagonal pairs on
     the ragged causal form, carrying state (rows that two waves compute are stored by their owner only)."""
     import torch
 
-    monkeypatch.delenv("FA_MASKED_W64", raising=False)
-    monkeypatch.delenv("FA_BLOCK_TUNED", raising=False)
+    fa_env(FA_MASKED_W64=None)
+    fa_env(FA_BLOCK_TUNED=None)
     name = fa.lib().fa_kernel_name_block_general
     assert name(511, 700, 128, 1, 700, 0) == b"fa::fa_fwd_w64_ragged_kernel"           # below the diagonal
     assert name(700, 700, 128, 1, 0, 0) == b"fa::fa_fwd_w64_ragged_causal_kernel"     # diagonal pair

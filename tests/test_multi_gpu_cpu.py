@@ -183,3 +183,45 @@ def test_ring_block_order():
     for w in (2, 8):
         for r in range(w):
             assert sorted(mg.ring_block_order(r, w)) == list(range(w))
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                          timeout=280, cwd=ROOT, env=e)
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no rank environment starts two rank processes itself (here: gloo ranks on
+    the CPU with a stand-in step, --selftest-cpu) and prints exactly one line, rank 0's, with n_gpus = 2."""
+    import json
+
+    r = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    assert j["per_rank_kernel_ms"] == [1.0, 2.0]  # gathered in rank order
+    assert "selftest" in j["data"] and j["value"] is None  # no kernel ran and the line says so
+
+
+def test_bench_launcher_fails_loudly_without_the_gpus():
+    """Asked for more GPUs than the node has, bench.py exits non-zero and prints no JSON line (it used to run one
+    rank and report n_gpus = 1)."""
+    import torch
+
+    n = torch.cuda.device_count()
+    r = _run_bench("--gpus", str(n + 2), "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "GPU" in r.stderr
+
+
+def test_bench_rank_rejects_a_world_that_is_not_gpus():
+    r = _run_bench("--gpus", "1", "--selftest-cpu", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

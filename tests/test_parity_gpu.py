@@ -61,9 +61,21 @@ def test_device_pointer_path_shapes(fa, oracle, torch_dev, shape):
     gate(oracle, oracle.attention_cpu(Q, K, V), O, str(shape))
 
 
+@pytest.fixture
+def ab_build(fa, monkeypatch):
+    """The comparison build of the library (make ab: -DFA_AB_KERNELS), which also holds the two register-staged
+    kernels that the product build leaves out.  The front end is pointed at it for one test."""
+    path = os.path.join(ROOT, "flash-attention_amd", "csrc", "libflash_attention_ab.so")
+    assert os.path.exists(path), "build it with make -C flash-attention_amd/csrc ab"
+    monkeypatch.setattr(fa, "_lib", fa.bind(path))
+    return fa
+
+
 @pytest.mark.parametrize("nwaves", ["4", "8"])
-def test_both_workgroup_sizes(fa, oracle, torch_dev, nwaves, monkeypatch):
-    monkeypatch.setenv("FA_NWAVES", nwaves)
+def test_both_workgroup_sizes(ab_build, oracle, torch_dev, nwaves, fa_env):
+    fa = ab_build
+    fa_env(FA_NWAVES=nwaves)
+    assert fa.lib().fa_kernel_name(512, 512) == (b"fa::fa_fwd_kernel<4>" if nwaves == "4" else b"fa::fa_fwd_w64_kernel")
     for shape in [(1, 2, 64, 128), (1, 3, 448, 128), (2, 8, 512, 128)]:
         Q, K, V = normal_fp16(12, shape)
         O = run_dev(fa, torch_dev, Q, K, V)
@@ -73,14 +85,15 @@ def test_both_workgroup_sizes(fa, oracle, torch_dev, nwaves, monkeypatch):
 @pytest.mark.parametrize("env,kernel", [
     ({"FA_W64": "1"}, b"fa::fa_fwd_w64_kernel"),  # (forced from three tiles on; by default from five)
     ({"FA_W64": "0"}, b"fa::fa_fwd_ring_kernel<8>"),
-    ({"FA_W64": "0", "FA_RING": "0"}, b"fa::fa_fwd_kernel<8>"),
+    ({"FA_W64": "0", "FA_RING": "0"}, b"fa::fa_fwd_kernel<8>"),  # (comparison build only)
 ])
-def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, monkeypatch):
+def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, fa_env, request):
     """The launcher's three kernels for 256-row query blocks, each on: few tiles per item, several
     items per workgroup (more items than CUs), rows whose maximum jumps from tile to tile, and
     bit-identical results across the variants' common shapes."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    if "FA_RING" in env:
+        fa = request.getfixturevalue("ab_build")
+    fa_env(**env)
     assert fa.lib().fa_kernel_name(512, 512) == kernel
     assert fa.lib().fa_kernel_name(256, 128) != b"fa::fa_fwd_w64_kernel"  # needs three tiles per item
     assert fa.lib().fa_kernel_name(320, 320) == kernel  # a last block of 64 rows: three waves without rows
@@ -287,13 +300,13 @@ def test_blockwise_entry_point(fa, oracle, torch_dev, nblocks):
 
 
 @pytest.mark.parametrize("Lk", [192, 256])
-def test_blockwise_shortest_items_many_per_workgroup(fa, oracle, torch_dev, Lk, monkeypatch):
+def test_blockwise_shortest_items_many_per_workgroup(fa, oracle, torch_dev, Lk, fa_env):
     """The one-wave-per-SIMD kernel at its minimum of three (and four) K/V tiles per item, with more
     items than workgroups (300 heads x one 256-row block on 256 CUs): every step is an item's first,
     last-but-one or last step, and some workgroups carry state across two items."""
     import torch
 
-    monkeypatch.setenv("FA_W64", "1")  # (below five tiles the launcher would pick the ring kernel)
+    fa_env(FA_W64="1")  # (below five tiles the launcher would pick the ring kernel)
     BH, Lq, D, nblk = 300, 256, 128, 2
     assert fa.lib().fa_kernel_name(Lq, Lk) == b"fa::fa_fwd_w64_kernel"
     rng = np.random.default_rng(Lk)

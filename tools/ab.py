@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of several builds of libflash_attention.so in ONE process.
 
-    python tools/ab.py --libs build_ab/a.so build_ab/b.so [--env FA_NWAVES=4 ...] --shapes 512 2048 16384
+    python tools/ab.py --libs build_ab/a.so build_ab/b.so [--env FA_W64=0 ...] --shapes 512 2048 16384
+
+(FA_NWAVES and FA_RING select the register-staged kernels, which only builds with -DFA_AB_KERNELS hold:
+flash-attention_amd/csrc/libflash_attention_ab.so, or tools/build_variant.sh NAME -DFA_AB_KERNELS.)
 
 Each (lib, env) pair is a variant; per shape the variants are timed round-robin
 (rounds x reps launches each) on the reference driver's input pattern, and the
@@ -74,12 +77,16 @@ def main():
         name, lib, e = variants[i]
         for kk, vv in e.items():
             os.environ[kk] = vv
+        if e:
+            lib.fa_debug_reload_env()  # (the switches are read once per process)
         if args.causal or args.lminus:
             rc = lib.fa_forward_general(p(q), p(k), p(v), p(outs[i]), B, H, L, L, D, int(args.causal), stream, None)
         else:
             rc = lib.fa_forward(p(q), p(k), p(v), p(outs[i]), B, H, L, D, 64, stream, None)
         for kk in e:
             os.environ.pop(kk, None)
+        if e:
+            lib.fa_debug_reload_env()
         assert rc == 0, (name, rc)
 
     for L in args.shapes:

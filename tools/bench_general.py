@@ -27,6 +27,7 @@ def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
     os.environ.pop("FA_MASKED_W64", None)
     if tuned_causal is not None:
         os.environ["FA_MASKED_W64"] = "1" if tuned_causal else "0"
+    fa.reload_env()  # (the switches are read once per process)
     m = B * H * L * D
     q, k, v, o = [t[:m].view(B, H, L, D) for t in buf]
     f = (lambda: fa.attention_general(q, k, v, causal=causal, out=o)) if general else (lambda: fa.attention(q, k, v, out=o))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time audit of fa_fwd_w64_kernel and its masked forms (causal, ragged, both), whose inline asm owns the accumulator registers.
+"""Build-time audit of fa_fwd_w64_kernel and its masked forms (causal, ragged, both) and its key-split form, whose inline asm owns the accumulator registers.
 
 The kernel names a[0:255] literally in its instruction strings; the compiler does not know they hold
 live values.  That is only sound while the compiler itself uses no accumulator register and spills
@@ -18,7 +18,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "flash-attention_amd", "csrc", "flash_attention_capi.hip")
 KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causal_kernelENS_9FwdParamsE",
-           "_ZN2fa24fa_fwd_w64_ragged_kernelENS_9FwdParamsE", "_ZN2fa31fa_fwd_w64_ragged_causal_kernelENS_9FwdParamsE"]
+           "_ZN2fa24fa_fwd_w64_ragged_kernelENS_9FwdParamsE", "_ZN2fa31fa_fwd_w64_ragged_causal_kernelENS_9FwdParamsE",
+           "_ZN2fa23fa_fwd_w64_split_kernelENS_9FwdParamsE"]
 
 
 def main():

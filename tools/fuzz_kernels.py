@@ -28,6 +28,8 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--causal", action="store_true")
 args = ap.parse_args()
 fa = ge.load_package()
+if not args.causal:  # the register-staged kernel (FA_RING=0) lives in the comparison build only
+    fa._lib = fa.bind(os.path.join(ROOT, "flash-attention_amd", "csrc", "libflash_attention_ab.so"))
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(args.seed)
 cpu = torch.Generator().manual_seed(args.seed)
@@ -39,6 +41,7 @@ if args.causal:
 def run(q, k, v, env):
     for a, b in env.items():
         os.environ[a] = b
+    fa.reload_env()  # (the switches are read once per process)
     try:
         if args.causal and env:
             return fa.attention_general(q, k, v, causal=mask)
@@ -46,6 +49,7 @@ def run(q, k, v, env):
     finally:
         for a in env:
             os.environ.pop(a, None)
+        fa.reload_env()
 
 bad = 0
 noise = [torch.randn((2, 8, 1024, 128), generator=g, device=dev).to(torch.float16) * 30 for _ in range(3)]
