@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "run_tensor_flash_attention_host_half",
     "fa_forward",
     "fa_forward_host_half",
+    "fa_forward_noalloc",
     "fa_forward_block",
     "fa_forward_general",
     "fa_forward_block_general",
@@ -83,6 +84,8 @@ def bind(path: str) -> ct.CDLL:
     for name in ("fa_forward", "fa_forward_host_half"):
         getattr(L, name).argtypes = sig
         getattr(L, name).restype = ct.c_int
+    L.fa_forward_noalloc.argtypes = sig[:-1]
+    L.fa_forward_noalloc.restype = ct.c_int
     L.fa_forward_block.argtypes = (
         [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 6 + [ct.c_void_p]
     )

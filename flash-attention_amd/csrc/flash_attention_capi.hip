@@ -144,6 +144,36 @@ extern "C" void fa_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
 constexpr size_t kSplitRowBytes = (size_t)fa::kHeadDim * sizeof(float) + 2 * sizeof(float);
 constexpr size_t kSplitMaxRows = 262144;  // virtual rows a split launch may take (136 MB of workspace)
 
+// Scratch buffer of fa_forward_noalloc: the workspace of a split launch for callers that must not allocate.
+// 65536 virtual rows (B = 1, H = 2, L = 16384 in two ranges; H = 1 in four) = 34 078 720 bytes, held by every
+// GPU the library runs on until the process ends.  `scratch` is a host-side stand-in for the array, not a device
+// address: host code only ever uses the per-device pointer that scratch_ptr() obtains from the runtime.
+constexpr size_t kScratchRows = 65536;
+constexpr size_t kScratchBytes = kScratchRows * kSplitRowBytes;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+// The array's address on the current device (every GPU holds its own copy at its own address), looked up
+// once per device with that device current.  nullptr (and the error text set) on failure.
+void* scratch_ptr() {
+    static std::atomic<void*> per_device[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        fail(FA_ERR_RUNTIME, "fa_forward_noalloc: no current device%s");
+        return nullptr;
+    }
+    void* ptr = per_device[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            std::snprintf(g_last_error, sizeof(g_last_error), "hipGetSymbolAddress(scratch) failed: %s",
+                          hipGetErrorString(e));
+            return nullptr;
+        }
+        per_device[dev].store(ptr, std::memory_order_release);  // (racing first calls store the same address)
+    }
+    return ptr;
+}
+
 // S for a launch of bh heads, q_blocks 256-row blocks per head and lk keys on `grid` resident workgroups;
 // 1 = no split.  Cost model in microseconds: a workgroup takes about 1.3 us per 64-key tile; a split adds a
 // second launch and the workspace traffic (written once, read once) at about 3 TB/s.  A range must keep eight
@@ -206,6 +236,7 @@ int launch_split(const fa::FwdParams& base, int S, void* ws, hipStream_t stream)
 enum class Workspace {
     kNone,     // blockwise calls and callers without one: never split
     kStream,   // allocate on the stream (hipMallocAsync / hipFreeAsync); no split if that fails
+    kScratch,  // the static per-device scratch buffer: nothing is allocated; too large a need is an error
 };
 
 int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Workspace::kNone) {
@@ -226,6 +257,18 @@ int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Worksp
         const int S = pick_split(p.bh, p.q_blocks, p.lq, p.lk, grid, kSplitMaxRows);
         if (S > 1) {
             const size_t bytes = (size_t)S * p.bh * p.lq * kSplitRowBytes;
+            if (wsk == Workspace::kScratch) {
+                // (the split is the one the allocating entry point would choose; it has to fit the static buffer)
+                if (bytes > kScratchBytes) {
+                    std::snprintf(g_last_error, sizeof(g_last_error),
+                                  "fa_forward_noalloc: this shape divides its keys %d ways and needs %zu bytes of "
+                                  "scratch; the static buffer holds %zu (use fa_forward)", S, bytes, kScratchBytes);
+                    return FA_ERR_WORKSPACE;
+                }
+                void* ws = scratch_ptr();
+                if (!ws) return FA_ERR_RUNTIME;
+                return launch_split(p, S, ws, stream);
+            }
             void* ws = nullptr;
             if (hipMallocAsync(&ws, bytes, stream) == hipSuccess && ws) {
                 const int rc = launch_split(p, S, ws, stream);
@@ -510,6 +553,25 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
     p.flags = 0;
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream, Workspace::kStream); });
+}
+
+int fa_forward_noalloc(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
+                       int D, int tile, void* stream_) {
+    g_last_error[0] = 0;
+    if (int rc = validate(B, H, L, D, tile)) return rc;
+    if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "fa_forward_noalloc: null tensor pointer%s");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    fa::FwdParams p{};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.bh = B * H;
+    p.lq = L;
+    p.lk = L;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.flags = 0;
+    return launch(p, stream, Workspace::kScratch);
 }
 
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,

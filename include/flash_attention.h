@@ -67,7 +67,8 @@ enum {
     FA_ERR_HEAD_DIM = 3,  /* D != 128 (the reference hard-codes it: cuda_utils.cuh:11) */
     FA_ERR_SHAPE = 4,     /* B or H <= 0, or sizes overflow */
     FA_ERR_POINTER = 5,   /* NULL tensor pointer */
-    FA_ERR_RUNTIME = 6    /* HIP runtime / launch failure; text in fa_last_error() */
+    FA_ERR_RUNTIME = 6,   /* HIP runtime / launch failure; text in fa_last_error() */
+    FA_ERR_WORKSPACE = 7  /* fa_forward_noalloc: the call needs more scratch memory than the static buffer holds */
 };
 
 /* Same work and arguments as run_tensor_flash_attention, but returns a status
@@ -84,6 +85,20 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
                int D, int tile, void* stream, float* elapsed_ms);
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
                          int H, int L, int D, int tile, void* stream, float* elapsed_ms);
+
+/* fa_forward for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid it.  No counterpart in the reference.  Same arguments, result and kernels as fa_forward
+ * (bit-identical output) minus elapsed_ms; it calls no hipMalloc / hipFree / hipMallocAsync or any other allocating
+ * routine, creates no events and never waits.  A launch that divides its keys (see fa_forward) takes its workspace
+ * from a buffer of 34 078 720 bytes that is part of the library's device image (65 536 query rows x ranges: B*H*L*S
+ * <= 65536, e.g. B=1, H=2, L=16384 in two ranges); every GPU the library runs on holds that buffer until the
+ * process ends.  A shape whose split needs more returns FA_ERR_WORKSPACE with the sizes in fa_last_error() and
+ * launches nothing; shapes that need no split (most: B*H*ceil(L/256) >= 512) use no scratch at all.  All calls on
+ * one GPU share the buffer: two calls that divide their keys and overlap in time on one GPU (different streams
+ * or host threads) race on it; calls on one stream are ordered and safe.  The first call on a device looks
+ * the buffer's address up and must not be made under stream capture. */
+int fa_forward_noalloc(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
+                       int D, int tile, void* stream);
 
 /* Blockwise forward: folds one K/V block of Lk keys into the carried online-
  * softmax state of Lq query rows, the rule of testing.cu:91-96 /
