@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--ring", action="store_true", help="sequence-parallel ring over the ranks (B=1, H=16)")
     ap.add_argument("--reserved-cus", type=int, default=None,
                     help="compute units the attention kernels leave free (default: 0; with --ring on more than one "
-                         "rank 16, for the exchange's transport kernels)")
+                         "rank 8, for the exchange's transport kernels)")
     ap.add_argument("--preheat-seconds", type=float, default=1.5,
                     help="untimed back-to-back launches before the warm-up steps, so that the chip's clock governor "
                          "has settled (0 disables)")
@@ -472,7 +472,7 @@ def run_ring(args, fa, torch, ranks, dev):
     if L % (64 * world) or L <= 0:
         raise SystemExit("--ring needs --seq-len divisible by 64 * (number of GPUs)")
     Lb = L // world
-    reserved = args.reserved_cus if args.reserved_cus is not None else (16 if world > 1 else 0)
+    reserved = args.reserved_cus if args.reserved_cus is not None else (8 if world > 1 else 0)
     fa.set_reserved_cus(reserved)
     q, k, v = [torch.empty((1, H, Lb, D), dtype=torch.float16, device=dev) for _ in range(3)]
     for t, seed in zip((q, k, v), (1234, 2345, 3456)):

@@ -404,6 +404,92 @@ __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int
     }
 }
 
+// The carried state of 32 rows (blockwise mode, key-split partials) through the same per-wave image, so that
+// global memory sees 256-byte pieces of whole rows instead of the 16-byte pieces a lane holds (lane = row:
+// 32 rows x 32 bytes per instruction).  An fp32 row is 512 bytes, twice the image's row, so the accumulator
+// goes in two column halves of 64; in each the chunk index 8 (db & 1) + 2 g4 + hh takes the place of the
+// fp16 output's 4 db + g4.  `row0` is the first of the 32 rows; rows below first_row are not stored.
+__device__ __forceinline__ void store_state_rows(const FwdParams& p, size_t row0, char* img, int lane,
+                                                 f32x16 (&oacc)[4], float m_run, float m_true, float l_run,
+                                                 int first_row = 0) {
+    // hand the state over relative to the true running max, whatever reference was in use
+    const float beta = __builtin_amdgcn_exp2f(m_run - m_true);
+    const float l_tot = half_wave_sum(l_run) * beta;
+    lane = opaque(lane);
+    const int r = lane & 31, hh = lane >> 5;
+    if (hh == 0 && r >= first_row) {
+        p.row_max[row0 + r] = m_true * 0.69314718055994530942f;
+        p.row_sum[row0 + r] = l_tot;
+    }
+    const int rrow = lane >> 4, ch = lane & 15;
+    const char* rd = img + rrow * kRowBytes;
+    int sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw[j] = ((ch ^ rrow) ^ (4 * j)) << 4;
+    float* wr = p.o_acc + (row0 + rrow) * kHeadDim + ch * 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = oacc[2 * half + dbl][4 * g4 + e] * beta;
+                *reinterpret_cast<f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh)) = t;
+            }
+        // (four rows-of-four at a time: this runs with the whole tile loop's state live)
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const u32x4*>(rd + (4 * grp + j) * 4 * kRowBytes + sw[j]);
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (first_row <= 0 || 4 * (4 * grp + j) + rrow >= first_row)
+                    *reinterpret_cast<u32x4*>(wr + (4 * grp + j) * 4 * kHeadDim + half * 64) = v[j];
+        }
+    }
+}
+// The way back: (o_acc, row_max, row_sum) of 32 rows into a sub-block's registers (what init_state does lane by
+// lane), row pieces of 256 bytes -> image -> fragments.
+__device__ __forceinline__ void load_state_rows(const FwdParams& p, size_t row0, char* img, int lane,
+                                                f32x16 (&oacc)[4], float& m_run, float& m_true, float& l_run) {
+    lane = opaque(lane);
+    const int r = lane & 31, hh = lane >> 5;
+    const float mx = p.row_max[row0 + r], sm = p.row_sum[row0 + r];
+    const int rrow = lane >> 4, ch = lane & 15;
+    char* wr = img + rrow * kRowBytes;
+    int sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw[j] = ((ch ^ rrow) ^ (4 * j)) << 4;
+    const float* rd = p.o_acc + (row0 + rrow) * kHeadDim + ch * 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const u32x4*>(rd + (4 * grp + j) * 4 * kHeadDim + half * 64);
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(wr + (4 * grp + j) * 4 * kRowBytes + sw[j]) = v[j];
+        }
+#pragma unroll
+        for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[2 * half + dbl][4 * g4 + e] = t[e];
+            }
+    }
+    m_run = mx * 1.44269504088896340736f;
+    m_true = m_run;
+    l_run = hh == 0 ? sm : 0.0f;
+}
+
 // Next item's Q rows travel global -> LDS directly (global_load_lds_dwordx4: no registers, 4 whole
 // rows per wave instruction).  The LDS side of such a load is linear (piece base + 16*lane), so the
 // image's XOR swizzle is applied to the SOURCE address: lane l of piece i fills slot l&15 of row

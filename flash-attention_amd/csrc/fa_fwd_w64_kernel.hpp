@@ -750,7 +750,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         if (needs_mask(0, lim)) apply_mask(sa0, sa1, mx_a, 0, lim);
     {
         f32x16 o[4];
-        init_state(p, wrow + g.r, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
+        if (p.flags & kFlagLoadState)  // (sub-block A's half of the image is free: its Q fragments are installed)
+            load_state_rows(p, wrow, img, lane, o, ra.m_run, ra.m_true, ra.l_run);
+        else
+            init_state(p, 0, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
         acc_store<kAccA>(o);
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -780,10 +783,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             const size_t r_ = (row_) + (off_);                                                 \
             f32x16 o_[4];                                                                      \
             acc_load<base_>(o_);                                                               \
-            if (p.flags & kFlagStoreState) {                                                   \
-                if (!RAGGED || (int)(off_) + g.r >= (skip_))                                   \
-                    finish_rows(p, r_ + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run); \
-            } else                                                                             \
+            if (p.flags & kFlagStoreState)                                                     \
+                store_state_rows(p, r_, (img_), lane, o_, (st_).m_run, (st_).m_true, (st_).l_run, \
+                                 RAGGED ? (skip_) - (int)(off_) : 0);                          \
+            else                                                                               \
                 store_output_rows(p.o + r_ * kHeadDim, (img_), lane, o_, (st_).l_run,          \
                                   RAGGED ? (skip_) - (int)(off_) : 0);                         \
         }                                                                                      \
@@ -791,11 +794,11 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // Start of an item for one sub-block, given the scaled row max mx_ of its first tile.  A fresh item
     // takes that max as its reference at once (nothing to rescale: O = 0, l = 0); a continued one
     // (blockwise mode) loads its state and decides as for any other tile.  Sets need_ accordingly.
-#define W64_INIT(base_, st_, row_, mx_, need_)                                                 \
+#define W64_INIT(base_, st_, row_, mx_, need_, img_)                                           \
     do {                                                                                       \
         if (p.flags & kFlagLoadState) {                                                        \
             f32x16 o_[4];                                                                      \
-            init_state(p, (row_) + g.r, g.hh, o_, (st_).m_run, (st_).m_true, (st_).l_run);     \
+            load_state_rows(p, (row_), (img_), lane, o_, (st_).m_run, (st_).m_true, (st_).l_run); \
             acc_store<base_>(o_);                                                              \
             need_ = rescale_needed(mx_, (st_).m_run);                                          \
         } else {                                                                               \
@@ -869,7 +872,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b);
             out_b = owns_rows(qb) ? wrow : kNoRows;
             if constexpr (RAGGED) skip_b = rows_skipped(qb);
-            W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b);
+            W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b, img + 32 * kRowBytes);
         }
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
 
@@ -908,7 +911,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #endif
                 return true;
             }
-            W64_INIT(kAccA, ra, nwrow, mx_a, need_a);
+            W64_INIT(kAccA, ra, nwrow, mx_a, need_a, img);
         }
         rescale_if_needed<kAccA>(need_a, mx_a, ra);
 

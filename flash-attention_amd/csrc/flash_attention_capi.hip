@@ -126,6 +126,18 @@ long persistent_grid() {
     const int k = g_reserved_cus.load(std::memory_order_relaxed);
     return (long)(k < cus ? cus - k : 1);
 }
+// The same for a launch of `items` equal items: the resident workgroups walk them in rounds, so the fewest
+// workgroups that still need no extra round finish at the same time and leave more units free (1024 items on
+// 248 units take 5 rounds; so do they on 208).  Kept a multiple of 8 where possible: workgroup ids congruent
+// mod 8 share an XCD, and the item order relies on that staying true from round to round.
+long balanced_grid(long items) {
+    const long maxg = persistent_grid();
+    if (items <= maxg) return items;
+    const long rounds = (items + maxg - 1) / maxg;
+    long g = (items + rounds - 1) / rounds;
+    g = (g + 7) & ~7L;
+    return g < maxg ? g : maxg;
+}
 
 #ifdef FA_STAMPS
 unsigned long long* g_stamps = nullptr;
@@ -219,8 +231,7 @@ int launch_split(const fa::FwdParams& base, int S, void* ws, hipStream_t stream)
     p.row_sum = p.row_max + vrows;
     p.flags = fa::kFlagStoreState;
     const long items = (long)p.bh * p.q_blocks;
-    long grid = persistent_grid();
-    if (grid > items) grid = items;
+    const long grid = balanced_grid(items);
     hipLaunchKernelGGL(fa::fa_fwd_w64_split_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     FA_HIP(hipGetLastError());
     long mgrid = (long)((rows + 7) / 8);
@@ -251,10 +262,10 @@ int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Worksp
     if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
     // Resident workgroups: registers and LDS admit one workgroup per CU.  More items than that are walked by
     // the resident workgroups as one stream.
-    long grid = switches().persistent ? persistent_grid() : items;
+    long grid = switches().persistent ? balanced_grid(items) : items;
     const KernelId kid = pick_kernel(nw, p.lq, p.lk);
     if (kid == kKernelW64 && wsk != Workspace::kNone && p.flags == 0 && switches().persistent) {
-        const int S = pick_split(p.bh, p.q_blocks, p.lq, p.lk, grid, kSplitMaxRows);
+        const int S = pick_split(p.bh, p.q_blocks, p.lq, p.lk, persistent_grid(), kSplitMaxRows);
         if (S > 1) {
             const size_t bytes = (size_t)S * p.bh * p.lq * kSplitRowBytes;
             if (wsk == Workspace::kScratch) {

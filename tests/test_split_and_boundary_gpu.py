@@ -309,3 +309,66 @@ def test_zigzag_ring_rank_compute_full_length(fa, oracle, dev, long_sequence):
         # (early rows of a causal sequence average few values: |O| reaches 2 to 5, where fp16 neighbours lie
         # 2e-3 to 4e-3 apart, so the absolute bound scales with |O| above 1)
         assert m["max_abs"] <= MAX_ABS_TOL * max(1.0, float(np.abs(ref).max())) and m["global_rel"] <= REL_L2_TOL, (c, m)
+
+
+# ------------------------------------------------------------------------------------------------
+# another stream's kernel beside the persistent attention kernels
+# ------------------------------------------------------------------------------------------------
+def test_side_stream_kernel_runs_inside_the_attention_window(fa, dev):
+    """The ring hands K/V on while it computes, through transport kernels of a collective library on another
+    stream.  The attention kernels are persistent (one workgroup per compute unit, each with the unit's whole LDS
+    and register file), so such a kernel finds no room until an attention kernel ends, unless units are left free:
+    with fa_set_reserved_cus(8) a kernel shaped like a transport kernel (8 workgroups x 512 threads, 32 KiB of LDS
+    each, copying one ring step's 134 MB) that becomes ready when the attention pass starts must finish before
+    the pass's FIRST kernel does, i.e. it ran beside it."""
+    import ctypes as ct_
+    import os
+
+    import torch
+
+    from conftest import ROOT
+
+    path = os.path.join(ROOT, "tests", "cpp", "libside_copy.so")
+    assert os.path.exists(path), "build it with make -C tests/cpp libside_copy.so"
+    side = ct_.CDLL(path)
+    side.side_copy_launch.argtypes = [ct_.c_void_p, ct_.c_void_p, ct_.c_size_t, ct_.c_int, ct_.c_int, ct_.c_int, ct_.c_int,
+                                      ct_.c_void_p]
+    H, Lb, D, steps = 16, 16384, 128, 4
+    q, k, v = [torch.empty((1, H, Lb, D), dtype=torch.float16, device=dev) for _ in range(3)]
+    for t, seed in zip((q, k, v), (1234, 2345, 3456)):
+        fa.init_half(t, seed)
+    src = torch.randn(2 * H * Lb * D, device=dev).to(torch.float16)
+    dst = torch.zeros_like(src)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    st = fa.BlockState(H, Lb, D, dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def run(reserved):
+        fa.set_reserved_cus(reserved)
+        st.first = True
+        for s in range(steps):  # warm-up pass
+            fa.attention_block(q, k, v, st, last=(s == steps - 1), stream=sa)
+        torch.cuda.synchronize()
+        a0, a_first, a1, b1 = ev(), ev(), ev(), ev()
+        a0.record(sa)
+        st.first = True
+        fa.attention_block(q, k, v, st, last=False, stream=sa)
+        a_first.record(sa)
+        for s in range(1, steps):
+            fa.attention_block(q, k, v, st, last=(s == steps - 1), stream=sa)
+        a1.record(sa)
+        sb.wait_event(a0)
+        assert side.side_copy_launch(src.data_ptr(), dst.data_ptr(), src.numel() * 2, 8, 512, 32768, 1, sb.cuda_stream) == 0
+        b1.record(sb)
+        torch.cuda.synchronize()
+        return a0.elapsed_time(b1), a0.elapsed_time(a_first), a0.elapsed_time(a1)
+
+    try:
+        side_done, first_done, all_done = run(8)
+        assert torch.equal(src, dst)
+        assert side_done < first_done < all_done, (side_done, first_done, all_done)
+        side0, first0, all0 = run(0)  # for the record: without free units the side kernel waits for a kernel boundary
+        print(f"reserved 8: side kernel done at {side_done:.3f} ms, first attention kernel at {first_done:.3f} ms, pass "
+              f"{all_done:.3f} ms; reserved 0: {side0:.3f} / {first0:.3f} / {all0:.3f} ms")
+    finally:
+        fa.set_reserved_cus(0)
