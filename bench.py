@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--preheat-seconds", type=float, default=1.5,
                     help="untimed back-to-back launches before the warm-up steps, so that the chip's clock governor "
                          "has settled (0 disables)")
+    ap.add_argument("--data", choices=["pattern", "normal"], default="pattern",
+                    help="inputs of the timed steps: the reference driver's pattern (default; what `value` is quoted "
+                         "on) or N(0,1) rounded to fp16 (compare_impls.py:84-87; for profiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip normal_data_tflops / reference_protocol_tflops")
@@ -386,7 +389,11 @@ def run_heads(args, fa, torch, ranks, dev):
     # gets its own window of the global tensors
     full = [torch.empty((BH_total, L, D), dtype=torch.float16, device=dev) for _ in range(3)]
     for t, seed in zip(full, (1234, 2345, 3456)):
-        fa.init_half(t, seed)
+        if args.data == "pattern":
+            fa.init_half(t, seed)
+        else:
+            t.copy_(torch.randn(t.shape, generator=torch.Generator(device=dev).manual_seed(seed), device=dev,
+                                dtype=torch.float32).to(torch.float16))
     q, k, v = [t[head0:head0 + bh_local].reshape(1, bh_local, L, D) for t in full]  # contiguous slabs
     o = torch.empty_like(q)
     torch.cuda.synchronize()
@@ -404,6 +411,8 @@ def run_heads(args, fa, torch, ranks, dev):
 
     result = base_result(args, world, value, wall_max)
     result["vs_baseline"] = (value / PUBLISHED_TFLOPS[L]) if (world == 1 and L in PUBLISHED_TFLOPS) else None
+    if args.data == "normal":
+        result["data"] = "synthetic, N(0,1) rounded to fp16"
     result["config"] = {
         "workload": f"B={B} H={H} L={L} D={D} fp16 in / fp32 accumulate, non-causal forward (README shape)",
         "per_gpu_heads": bh_local,

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "fa_forward_noalloc",
     "fa_forward_block",
     "fa_forward_general",
+    "fa_forward_varlen",
     "fa_forward_block_general",
     "fa_forward_general_host_half",
     "run_naive_attention_host_half",
@@ -92,6 +93,9 @@ def bind(path: str) -> ct.CDLL:
     L.fa_forward_block.restype = ct.c_int
     L.fa_forward_general.argtypes = [HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 + [ct.c_void_p, FloatPtr]
     L.fa_forward_general.restype = ct.c_int
+    L.fa_forward_varlen.argtypes = ([HalfPtr, HalfPtr, HalfPtr, HalfPtr] + [ct.c_int] * 6 +
+                                    [ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.c_void_p, FloatPtr])
+    L.fa_forward_varlen.restype = ct.c_int
     L.fa_forward_block_general.argtypes = (
         [HalfPtr, HalfPtr, HalfPtr, HalfPtr, FloatPtr, FloatPtr, FloatPtr] + [ct.c_int] * 9 + [ct.c_void_p]
     )
@@ -243,6 +247,37 @@ def attention_general(q, k, v, causal: bool = False, out=None, stream=None, time
         rc = lib().fa_forward_general(
             _dev_half_ptr(q), _dev_half_ptr(k), _dev_half_ptr(v), _dev_half_ptr(out), B, H, Lq, Lk, D,
             FLAG_CAUSAL if causal else 0, _stream_handle(stream), ct.byref(ms) if timed else None,
+        )
+    _check(rc)
+    return (out, float(ms.value)) if timed else out
+
+
+def attention_varlen(q, k, v, q_len=None, k_len=None, causal: bool = False, out=None, stream=None, timed: bool = False):
+    """``fa_forward_varlen``: padded batches.  q [B,H,Lq,D], k, v [B,H,Lk,D] contiguous fp16 GPU tensors; ``q_len`` /
+    ``k_len`` int32 GPU tensors of B valid lengths (or None).  Rows of ``out`` from ``q_len[b]`` on are left as
+    they are.  Returns ``out`` (and the kernel-only milliseconds when ``timed``)."""
+    import torch
+
+    for t in (q, k, v):
+        if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+            raise ValueError("q, k, v must be contiguous float16 GPU tensors; there is no CPU fallback")
+    B, H, Lq, D = q.shape
+    Lk = k.shape[2]
+    if k.shape != (B, H, Lk, D) or v.shape != k.shape:
+        raise ValueError("k, v must be [B,H,Lk,D] with q's B, H, D")
+    for t in (q_len, k_len):
+        if t is not None and (not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous() or t.numel() != B):
+            raise ValueError("q_len / k_len must be contiguous int32 GPU tensors of B entries")
+    if out is None:
+        out = torch.zeros_like(q)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device)
+    ip = lambda t: ct.cast(ct.c_void_p(t.data_ptr()), ct.POINTER(ct.c_int)) if t is not None else None
+    ms = ct.c_float(0.0)
+    with torch.cuda.device(q.device):
+        rc = lib().fa_forward_varlen(
+            _dev_half_ptr(q), _dev_half_ptr(k), _dev_half_ptr(v), _dev_half_ptr(out), B, H, Lq, Lk, D,
+            FLAG_CAUSAL if causal else 0, ip(q_len), ip(k_len), _stream_handle(stream), ct.byref(ms) if timed else None,
         )
     _check(rc)
     return (out, float(ms.value)) if timed else out

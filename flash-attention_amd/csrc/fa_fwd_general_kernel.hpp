@@ -136,16 +136,26 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
     // Under the causal mask block qb costs qb + 1 units: hand the long blocks out first, so that the
     // workgroups still running at the end are the short ones.
     if (causal) qb = p.q_blocks - 1 - qb;
+    // Padded batches: this head's sequence uses its first lq_v query rows and lk_v keys; p.lq and p.lk
+    // remain the strides.  Rows from lq_v on are neither computed nor stored; a sequence without keys
+    // gives O = 0.
+    int lq_v = p.lq, lk_v = p.lk;
+    if (p.q_len || p.k_len) {
+        const int batch = head / p.heads_per_batch;
+        if (p.q_len) lq_v = min(max(p.q_len[batch], 0), p.lq);
+        if (p.k_len) lk_v = min(max(p.k_len[batch], 0), p.lk);
+        if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier)
+    }
     const int q_row0 = qb * QB + wave * kRowsPerWave;       // wave-uniform
-    const bool wave_valid = q_row0 < p.lq;
-    const int q_abs = min(q_row0 + g.r, p.lq - 1);           // this lane's query row (clamped)
+    const bool wave_valid = q_row0 < lq_v;
+    const int q_abs = min(q_row0 + g.r, lq_v - 1);           // this lane's query row (clamped)
     // key indices are relative to this block of keys; a negative limit means the row sees none of them
     const int shift = p.q_pos0 - p.k_pos0;
-    const int wave_last = min(q_row0 + kRowsPerWave - 1, p.lq - 1) + shift;  // last key any row of the wave may see
-    const int key_limit = causal ? min(p.lk - 1, q_abs + shift) : p.lk - 1;  // last key this row may see
+    const int wave_last = min(q_row0 + kRowsPerWave - 1, lq_v - 1) + shift;  // last key any row of the wave may see
+    const int key_limit = causal ? min(lk_v - 1, q_abs + shift) : lk_v - 1;  // last key this row may see
 
-    int n_tiles = (p.lk + kKvTile - 1) / kKvTile;
-    if (causal) n_tiles = max(0, min(n_tiles, (min(qb * QB + QB, p.lq) + shift + kKvTile - 1) / kKvTile));
+    int n_tiles = (lk_v + kKvTile - 1) / kKvTile;
+    if (causal) n_tiles = max(0, min(n_tiles, (min(qb * QB + QB, lq_v) + shift + kKvTile - 1) / kKvTile));
 
     const half_t* kh = p.k + (size_t)head * p.lk * D;
     const half_t* vh = p.v + (size_t)head * p.lk * D;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
     auto stage_load = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < CHUNKS; ++i) {
-            const int row = min(tile * kKvTile + st_row + i * RSTEP, p.lk - 1);
+            const int row = min(tile * kKvTile + st_row + i * RSTEP, lk_v - 1);
             const size_t off = (size_t)row * D + st_ch * 8;
             st_k[i] = *reinterpret_cast<const u32x4*>(kh + off);
             st_v[i] = *reinterpret_cast<const u32x4*>(vh + off);
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel
         buf ^= 1;
     }
 
-    const bool row_valid = wave_valid && q_row0 + g.r < p.lq;
+    const bool row_valid = wave_valid && q_row0 + g.r < lq_v;
     if (p.flags & kFlagStoreState) {
         // hand the state over relative to the true running max, whatever reference was in use
         const float beta = __builtin_amdgcn_exp2f(m_run - m_true);

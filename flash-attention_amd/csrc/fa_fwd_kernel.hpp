@@ -68,6 +68,11 @@ struct FwdParams {
     unsigned long long* stamps;  // diagnostic builds only (FA_STAMPS): 32 time stamps per workgroup
     int q_pos0, k_pos0;  // absolute position of query row 0 / key row 0 (causal mask of fa_fwd_general_kernel only)
     int k_splits, lk_split, bh_real;  // fa_fwd_w64_split_kernel only: key ranges per head, keys per range, real heads
+    // fa_fwd_general_kernel only (padded batches): per-batch valid lengths, device arrays of bh / heads_per_batch
+    // entries or null (= lq / lk for every batch); lq and lk stay the padded lengths, i.e. the strides
+    const int* q_len;
+    const int* k_len;
+    int heads_per_batch;
 };
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second.

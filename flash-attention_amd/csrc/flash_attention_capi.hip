@@ -613,6 +613,34 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 
+int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int Lq,
+                      int Lk, int D, int flags, const int* d_q_len, const int* d_k_len, void* stream_,
+                      float* elapsed_ms) {
+    g_last_error[0] = 0;
+    if (D != 64 && D != 128 && D != 256) return fail(FA_ERR_HEAD_DIM, "fa_forward_varlen: D must be 64, 128 or 256%s");
+    if (Lq <= 0 || Lk <= 0) return fail(FA_ERR_SEQLEN, "fa_forward_varlen: Lq and Lk must be positive%s");
+    if (flags & ~FA_FLAG_CAUSAL) return fail(FA_ERR_SHAPE, "fa_forward_varlen: unknown flag%s");
+    if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "fa_forward_varlen: B and H must be positive%s");
+    if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "fa_forward_varlen: B*H too large%s");
+    if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "fa_forward_varlen: null tensor pointer%s");
+    if (!d_q_len && !d_k_len)  // nothing is padded: the general entry point's own routes (it wants Lq == Lk under the mask)
+        return fa_forward_general(dQ, dK, dV, dO, B, H, Lq, Lk, D, flags, stream_, elapsed_ms);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    fa::FwdParams p{};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.bh = B * H;
+    p.lq = Lq;
+    p.lk = Lk;
+    p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
+    p.q_len = d_q_len;
+    p.k_len = d_k_len;
+    p.heads_per_batch = H;
+    return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
+}
+
 int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, float* o_acc,
                              float* row_max, float* row_sum, int BH, int Lq, int Lk, int D, int flags, int q_pos0,
                              int k_pos0, int first, int last, void* stream_) {

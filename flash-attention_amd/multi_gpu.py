@@ -55,6 +55,37 @@ def sharded_forward(q, k, v, rank: int, world: int, attention_fn: Optional[Calla
     return start, stop, attention_fn(qs, ks, vs)
 
 
+# Compute units the attention kernels leave free while a ring exchanges K/V.  The D = 128 kernels are persistent: one
+# workgroup per compute unit, each holding the unit's whole LDS and register file, so a transport kernel of the
+# collective library finds no room until an attention kernel ends and the hand-off would queue behind the compute
+# instead of running beside it.  Measured on one MI355X with a transport-shaped kernel (8 workgroups x 512 threads,
+# 32 KiB LDS, 134 MB): with 8 units free it runs beside the attention kernel; a ring pass of 8 steps at
+# L = 131072 then takes 13.1 ms instead of 12.0 ms (1024 equal items no longer divide by the workgroup count).
+RING_RESERVED_CUS = 8
+
+
+class _reserved_cus:
+    """with _reserved_cus(k): ...  (no-op for k == 0 or when a caller has already reserved units)"""
+
+    def __init__(self, k):
+        self.k, self.fa, self.active = k, None, False
+
+    def __enter__(self):
+        if self.k > 0:
+            import flash_attention_amd as fa
+
+            self.fa = fa
+            if fa.lib().fa_get_reserved_cus() == 0:
+                fa.set_reserved_cus(self.k)
+                self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.fa.set_reserved_cus(0)
+        return False
+
+
 def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_factory: Optional[Callable] = None):
     """Sequence-parallel forward.  q,k,v: this rank's rows, contiguous [B,H,L/P,D].
     Returns this rank's rows of O.
@@ -67,6 +98,7 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
     import torch
     import torch.distributed as dist
 
+    reserve = 0
     if step_fn is None or state_factory is None:
         import flash_attention_amd as fa
 
@@ -74,6 +106,7 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
         # to the tuned kernels (whole tiles, and ragged lengths where those win)
         step_fn = step_fn or fa.attention_block_general
         state_factory = state_factory or fa.BlockState
+        reserve = RING_RESERVED_CUS
 
     # (no process group: a single rank, which folds its own block and is done)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -90,20 +123,21 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
     cur = torch.stack((k, v)).contiguous()
     spare = torch.empty_like(cur)
     out = None
-    for s in range(world):
-        last = s == world - 1
-        reqs = []
-        if not last:
-            # issued before the compute of this step, so the transfer overlaps it; the
-            # backend orders it after the previous step's kernel, which was the last reader
-            # of `spare`
-            ops = [dist.P2POp(dist.isend, cur, nxt, group), dist.P2POp(dist.irecv, spare, prv, group)]
-            reqs = dist.batch_isend_irecv(ops)
-        out = step_fn(q, cur[0], cur[1], state, last)
-        for r in reqs:
-            r.wait()
-        if not last:
-            cur, spare = spare, cur
+    with _reserved_cus(reserve):
+        for s in range(world):
+            last = s == world - 1
+            reqs = []
+            if not last:
+                # issued before the compute of this step, so the transfer can run beside it (the attention kernels
+                # leave RING_RESERVED_CUS units free for its kernels); the backend orders it after the previous
+                # step's kernel, which was the last reader of `spare`
+                ops = [dist.P2POp(dist.isend, cur, nxt, group), dist.P2POp(dist.irecv, spare, prv, group)]
+                reqs = dist.batch_isend_irecv(ops)
+            out = step_fn(q, cur[0], cur[1], state, last)
+            for r in reqs:
+                r.wait()
+            if not last:
+                cur, spare = spare, cur
     return out
 
 
@@ -165,6 +199,7 @@ def ring_forward_causal(q2, k2, v2, group=None, step_fn: Optional[Callable] = No
     import torch
     import torch.distributed as dist
 
+    use_gpu_defaults = step_fn is None or state_factory is None
     if step_fn is None or state_factory is None:
         import flash_attention_amd as fa
 
@@ -176,6 +211,7 @@ def ring_forward_causal(q2, k2, v2, group=None, step_fn: Optional[Callable] = No
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    reserve = RING_RESERVED_CUS if use_gpu_defaults and world > 1 else 0
     Lc = q2.shape[3]
     nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
     prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
@@ -197,4 +233,5 @@ def ring_forward_causal(q2, k2, v2, group=None, step_fn: Optional[Callable] = No
             box["reqs"] = dist.batch_isend_irecv(ops)
         return box["cur"]
 
-    return run_zigzag_steps(q2, kv_of_step, rank, world, Lc, step_fn, state_factory)
+    with _reserved_cus(reserve):
+        return run_zigzag_steps(q2, kv_of_step, rank, world, Lc, step_fn, state_factory)

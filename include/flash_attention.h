@@ -133,6 +133,20 @@ enum { FA_FLAG_CAUSAL = 1 };
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream, float* elapsed_ms);
 
+/* Padded batches (the padding mask): sequence b of the batch uses only its first q_len[b] query rows and its first
+ * k_len[b] keys of the padded [B][H][Lq][D] / [B][H][Lk][D] tensors; what lies behind them is never read (keys,
+ * values) or written (rows of dO from q_len[b] on keep their bytes).  Per sequence the result is what
+ * attention_cpu gives on the truncated tensors: its 64-key tiles end at the sequence's last key
+ * (testing.cu:65-66).  d_q_len and d_k_len are DEVICE arrays of B ints, read by the kernel (no host
+ * synchronisation); either may be NULL (= Lq, Lk for every sequence); values are clamped to [0, Lq] and [0, Lk]; a
+ * sequence without keys gets O = 0.  With FA_FLAG_CAUSAL key j is visible to query i iff j <= i (both counted from
+ * the sequence's start; Lq and Lk may differ).  D of 64, 128 or 256.  The reference has no mask of this kind: its
+ * README lists "causal and padding masks" as future work (README.md:44), its naive kernel knows the causal one
+ * only (normal_attention.cu:50,64,81). */
+int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int Lq,
+                      int Lk, int D, int flags, const int* d_q_len, const int* d_k_len, void* stream,
+                      float* elapsed_ms);
+
 /* Blockwise form of fa_forward_general (the state and the first/last convention of fa_forward_block,
  * any Lq, Lk >= 1, D of 64, 128 or 256).  With FA_FLAG_CAUSAL key j of this block is visible to query
  * i of this block iff k_pos0 + j <= q_pos0 + i, the positions being those of the rows in the whole

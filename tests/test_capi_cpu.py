@@ -110,3 +110,19 @@ def test_flop_formula(fa):
     # benchmark_tensor_flash_attention.cu:218
     assert fa.attention_flops(32, 16, 512, 128) == 4.0 * 512 * 512 * 128 * 16 * 32
     assert round(fa.attention_flops(1, 16, 16384, 128) / 1e12, 3) == 2.199
+
+
+def test_varlen_and_noalloc_validation(fa):
+    """Bad arguments of the padded-batch and the no-allocation entry points are refused before any device work."""
+    L = fa.lib()
+    buf = np.zeros(16, dtype=np.float16)
+    p = buf.ctypes.data_as(fa.HalfPtr)
+    assert L.fa_forward_varlen(p, p, p, p, 1, 1, 64, 64, 96, 0, None, None, None, None) == 3
+    assert L.fa_forward_varlen(p, p, p, p, 1, 1, 0, 64, 128, 0, None, None, None, None) == 2
+    assert L.fa_forward_varlen(p, p, p, p, 0, 1, 64, 64, 128, 0, None, None, None, None) == 4
+    assert L.fa_forward_varlen(p, p, p, p, 1, 1, 64, 64, 128, 2, None, None, None, None) == 4
+    assert L.fa_forward_varlen(p, p, p, None, 1, 1, 64, 64, 128, 0, None, None, None, None) == 5
+    assert L.fa_forward_noalloc(p, p, p, p, 1, 1, 64, 128, 32, None) == 1 and b"tile must be 64" in L.fa_last_error()
+    assert L.fa_forward_noalloc(p, p, p, p, 1, 1, 100, 128, 64, None) == 2
+    assert L.fa_forward_noalloc(p, p, p, None, 1, 1, 64, 128, 64, None) == 5
+    assert L.fa_set_reserved_cus(-1) == 4

@@ -501,3 +501,81 @@ def test_ring_forward_default_step_takes_any_length(fa, dev, tmp_path):
         assert torch.equal(out, fa.attention_general(q, k, v))
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# padded batches (fa_forward_varlen)
+# ------------------------------------------------------------------------------------------------
+def _varlen_case(fa, oracle, dev, B, H, Lq, Lk, D, q_lens, k_lens, causal, seed):
+    """Sequences of mixed lengths in one padded batch; the padding holds NaN (keys, values, queries) and the
+    output a sentinel.  Per sequence: the oracle on the truncated tensors; behind q_len the sentinel stays."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    Q = rng.standard_normal((B, H, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    Qp, Kp, Vp = Q.copy(), K.copy(), V.copy()
+    for b in range(B):
+        Qp[b, :, q_lens[b]:] = np.nan
+        Kp[b, :, k_lens[b]:] = np.nan
+        Vp[b, :, k_lens[b]:] = np.nan
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Qp, Kp, Vp)]
+    o = torch.full((B, H, Lq, D), 123.0, dtype=torch.float16, device=dev)
+    ql = torch.tensor(q_lens, dtype=torch.int32, device=dev)
+    kl = torch.tensor(k_lens, dtype=torch.int32, device=dev)
+    fa.attention_varlen(q, k, v, ql, kl, causal=causal, out=o)
+    torch.cuda.synchronize()
+    O = o.cpu().numpy()
+    for b in range(B):
+        nq, nk = q_lens[b], k_lens[b]
+        assert (O[b, :, nq:] == 123.0).all(), f"sequence {b}: wrote behind its last query row"
+        if nq == 0:
+            continue
+        if nk == 0:
+            assert (O[b, :, :nq] == 0).all(), f"sequence {b}: no keys must give 0"
+            continue
+        Qs, Ks, Vs = [np.ascontiguousarray(a[b:b + 1, :, :n]) for a, n in ((Q, nq), (K, nk), (V, nk))]
+        if nq == nk:
+            ref = oracle.attention_cpu(Qs, Ks, Vs, causal=causal)
+        else:  # attention_cpu wants one length: fold the keys into a state of the nq rows (no mask)
+            assert not causal
+            st = oracle.BlockState(1, H, nq, D)
+            oracle.block_update(st, Qs, Ks, Vs)
+            ref = oracle.block_finalize(st)
+        gate(oracle, ref, O[b:b + 1, :, :nq], f"sequence {b} (q_len {nq}, k_len {nk}, causal {causal})")
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_padded_batch_mixed_lengths(fa, oracle, dev, D, causal):
+    """Lengths below 192, not multiples of 64, a full-length one, a single row, and an empty sequence in one batch."""
+    lens = [700, 1, 191, 64, 0, 513, 640, 100]
+    _varlen_case(fa, oracle, dev, 8, 3, 700, 700, D, lens, lens, causal, seed=900 + D)
+
+
+def test_padded_batch_different_query_and_key_lengths(fa, oracle, dev):
+    q_lens = [300, 17, 256, 1]
+    k_lens = [511, 200, 0, 65]
+    _varlen_case(fa, oracle, dev, 4, 2, 300, 512, 128, q_lens, k_lens, False, seed=77)
+
+
+def test_padded_batch_only_key_lengths_given(fa, oracle, dev):
+    """k_len alone (q_len NULL): every query row of the padded tensor is computed against its sequence's keys."""
+    import torch
+
+    B, H, L, D = 3, 2, 320, 128
+    Q, K, V = normal_fp16(55, (B, H, L, D))
+    k_lens = [320, 130, 1]
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = fa.attention_varlen(q, k, v, None, torch.tensor(k_lens, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    for b in range(B):
+        st = oracle.BlockState(1, H, L, D)
+        oracle.block_update(st, np.ascontiguousarray(Q[b:b + 1]), np.ascontiguousarray(K[b:b + 1, :, :k_lens[b]]),
+                            np.ascontiguousarray(V[b:b + 1, :, :k_lens[b]]))
+        gate(oracle, oracle.block_finalize(st), o[b:b + 1].cpu().numpy(), f"sequence {b}")
+    # no lengths at all: the unpadded entry point's result
+    o2 = fa.attention_varlen(q, k, v)
+    torch.cuda.synchronize()
+    assert torch.equal(o2, fa.attention_general(q, k, v))
