@@ -251,8 +251,12 @@ def cpu_baseline(B, H, L, target_s):
     n_heads = int(max(1, min(B * H, target_s / t_probe)))
     n = n_heads * L * D
     Q, K, V = [oracle.init_half(n, s).reshape(1, n_heads, L, D) for s in (1234, 2345, 3456)]
-    # when even the whole workload is short on this host, repeat it until ~target_s has been spent
-    reps = int(max(1, min(50, target_s / max(t_probe * n_heads, 1e-3))))
+    # when even the whole workload is short on this host, repeat it until ~target_s has been spent (the probe
+    # above also paid for starting the threads, so one pass of the sample is timed before deciding)
+    t = time.perf_counter()
+    oracle.attention_cpu(Q, K, V, nthreads=0)
+    t_pass = max(time.perf_counter() - t, 1e-3)
+    reps = int(max(1, min(200, target_s / t_pass)))
     t = time.perf_counter()
     for _ in range(reps):
         oracle.attention_cpu(Q, K, V, nthreads=0)
