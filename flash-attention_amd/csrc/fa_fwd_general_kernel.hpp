@@ -113,8 +113,11 @@ __device__ __forceinline__ void pv_tile_d(const char* vb, const LaneGeomD<D>& g,
     }
 }
 
+#ifndef FA_GEN64_OCC
+#define FA_GEN64_OCC 2
+#endif
 template <int D>
-__global__ __launch_bounds__(256, (D == 256 ? 1 : 2)) void fa_fwd_general_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, (D == 256 ? 1 : D == 64 ? FA_GEN64_OCC : 2)) void fa_fwd_general_kernel(const FwdParams p) {
     using HD = HeadDim<D>;
     constexpr int NWAVES = 4;
     constexpr int NT = NWAVES * 64;

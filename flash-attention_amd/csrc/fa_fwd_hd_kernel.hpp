@@ -1,0 +1,334 @@
+// Forward kernel for head dims 64 and 256, whole tiles, no mask (fa_forward_general with Lq % 64 == 0,
+// Lk % 64 == 0).  The reference fixes D = 128 (cuda_utils.cuh:11) and lists other head dims as future work
+// (README.md:47); fa_fwd_general_kernel<D> serves them for every shape, this kernel serves the whole-tile shapes
+// faster.
+//
+// What it keeps from the D = 128 kernels: transposed scores S^T = K.Q^T with v_mfma_f32_32x32x16_f16, P straight
+// from the score registers into O^T += V^T.P^T, K/V tiles travelling global -> LDS by DMA (global_load_lds_dwordx4,
+// swizzle applied on the source side, hidden from the compiler and awaited by hand) into a ring of stages, one
+// barrier per step, the deferred rescale.  What differs:
+//   * a stage is one K tile and one V tile of TK keys, 16 KiB each whatever the head dim: TK = 128 keys for D = 64,
+//     32 keys for D = 256;
+//   * one workgroup per (head, query block), not persistent: Q fragments come straight from global memory, the
+//     output goes straight back (these shapes are long enough for the item boundary not to matter);
+//   * the two matrix products of a tile are software-pipelined INSIDE a wave: while the matrix pipe computes the
+//     next tile's scores, the vector ALU turns the current tile's scores into probabilities; while it multiplies
+//     those with V, the vector ALU takes the next scores' row max.  D = 256 needs this because its 128
+//     accumulator registers per 32 rows leave room for one wave per SIMD only (no second wave to overlap with);
+//     the instruction mix is left to the compiler's scheduler, guided by sched_group_barrier.
+#pragma once
+#include "fa_fwd_general_kernel.hpp"
+#include "fa_fwd_ring_kernel.hpp"
+#include "fa_fwd_w64_kernel.hpp"  // static_for
+
+namespace fa {
+
+template <int D>
+struct HdCfg;
+template <>
+struct HdCfg<256> {
+    static constexpr int kWaves = 4;    // 32 rows each: 128-row query blocks, one wave per SIMD
+    static constexpr int kTk = 32;      // keys per tile
+    static constexpr int kStages = 3;   // 3 x 32 KiB
+    static constexpr int kOcc = 1;
+};
+template <>
+struct HdCfg<64> {
+    static constexpr int kWaves = 4;    // as above; the vector ALU binds here (one exponential per 256 FLOP)
+    static constexpr int kTk = 128;
+    static constexpr int kStages = 3;
+    static constexpr int kOcc = 1;
+};
+
+// All MFMAs are inline asm with explicit register files, as in fa_fwd_w64_kernel: the O^T accumulator lives in
+// accumulator registers a[0 : 16 * D/32 - 1] that the asm strings name literally (the compiler never sees them, so it
+// cannot re-home them into architectural registers with copies around every MFMA, which is what it does to an
+// accumulator that ordinary vector code also touches, here the rescale); scores stay in architectural registers.
+// tools/check_owned_regs.py audits this kernel too.
+__device__ __forceinline__ void mfma_vv_first(f32x16& d, const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_vv(f32x16& d, const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
+// a[LO : LO+15] = 0 through the matrix pipe; a[BASE : BASE+N-1] *= alpha through the vector ALU (rare: the rescale).
+template <int LO>
+__device__ __forceinline__ void acc_zero16() {
+    half8 z = {};
+    asm volatile("s_nop 3" : "+v"(z));  // wait states between the vector writes of z and the MFMA reading it
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%1:%2], %0, %0, 0" : : "v"(z), "n"(LO), "n"(LO + 15));
+}
+template <int BASE, int N>
+__device__ __forceinline__ void acc_scale_n(float alpha) {
+    acc_fence();
+    static_for<N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        acc_put<BASE + i>(acc_get<BASE + i>() * alpha);
+    });
+}
+
+// Scores of one tile, nothing beside them (the prologue): S^T = K.Q^T for KB key blocks, D / 16 k-steps.
+template <int D, int KB>
+__device__ __forceinline__ void hd_scores(const char* kb, const LaneGeomD<D>& g, const half8 (&qf)[HeadDim<D>::kSteps],
+                                          f32x16 (&s)[KB]) {
+    using HD = HeadDim<D>;
+    static_for<HD::kSteps * KB>([&](auto ic) {
+        constexpr int gi = decltype(ic)::value, b = gi % KB, ks = gi / KB;
+        const half8 a = *reinterpret_cast<const half8*>(kb + g.k_rd[ks] + b * 32 * HD::kRow);
+        if constexpr (ks == 0)
+            mfma_vv_first(s[b], a, qf[ks]);
+        else
+            mfma_vv(s[b], a, qf[ks]);
+    });
+#pragma unroll
+    for (int b = 0; b < KB; ++b) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[b]));  // MFMA result -> vector reader
+}
+
+// Row max of raw scores (one query row per lane pair), scaled to the log2 domain.
+template <int KB>
+__device__ __forceinline__ float hd_row_max(const f32x16 (&s)[KB], float c) {
+    float a = fmaxf(s[0][0], s[0][1]);
+#pragma unroll
+    for (int b = 0; b < KB; ++b)
+#pragma unroll
+        for (int e = (b == 0 ? 2 : 0); e < 16; e += 2) a = fmaxf(fmaxf(a, s[b][e]), s[b][e + 1]);
+    return half_wave_max(a) * c;
+}
+
+template <int D, int KB>
+__device__ __forceinline__ half8 hd_read_v(const char* vb, const LaneGeomD<D>& g, int i) {
+    using HD = HeadDim<D>;
+    const int kk = i / HD::kBlocks, db = i % HD::kBlocks;
+    const char* a0 = vb + g.v_rd[db] + kk * 16 * HD::kRow;
+    const short4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a0));
+    const short4_t t1 =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a0 + 8 * HD::kRow));
+    return __builtin_bit_cast(half8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// Block 1 of a step, written out gap by gap (sched_barrier(0) after each):
+//   matrix pipe   S_next = K(t+1).Q^T                     (NS = KB * D/16 MFMAs, K fragments read KA ahead)
+//   vector ALU    p = exp2(S_cur c - m), row sum, P^T     (16 KB elements spread over the gaps; an element is summed
+//                                                          one gap after its exponential, a pair rounded to fp16
+//                                                          one gap after that)
+// With NEXT = false (the last tile) only the vector side runs.
+template <int D, int KB, bool NEXT>
+__device__ __forceinline__ void hd_block1(const char* kb, const LaneGeomD<D>& g, const half8 (&qf)[HeadDim<D>::kSteps],
+                                          f32x16 (&s_next)[KB], f32x16 (&s_cur)[KB], float c, float m_run, float& l_run,
+                                          half8 (&pf)[2 * KB]) {
+    using HD = HeadDim<D>;
+    constexpr int NS = HD::kSteps * KB, NE = 16 * KB, KA = 4;
+    const float nm = -m_run;
+    float sum = 0.0f;
+    u32x4 pw[2 * KB] = {};
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    half8 kf[KA];
+    auto k_frag = [&](auto ic) -> half8 {
+        constexpr int gi = decltype(ic)::value, b = gi % KB, ks = gi / KB;
+        return *reinterpret_cast<const half8*>(kb + g.k_rd[ks] + b * 32 * HD::kRow);
+    };
+    if constexpr (NEXT) static_for<KA>([&](auto ic) { kf[decltype(ic)::value] = k_frag(ic); });
+    auto started = [](int gp) constexpr { return gp <= 0 ? 0 : (gp >= NS ? NE : gp * NE / NS); };
+    auto convert_pair = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const f32x2 pr = {s_cur[(2 * q) / 16][(2 * q) % 16], s_cur[(2 * q + 1) / 16][(2 * q + 1) % 16]};
+        const half2_t h = __builtin_convertvector(pr, half2_t);
+        pw[q / 4][q % 4] = __builtin_bit_cast(unsigned, h);
+    };
+    static_for<NS>([&](auto ic) {
+        constexpr int gi = decltype(ic)::value;
+        if constexpr (NEXT) {
+            constexpr int b = gi % KB, ks = gi / KB;
+            if constexpr (ks == 0)
+                mfma_vv_first(s_next[b], kf[gi % KA], qf[ks]);
+            else
+                mfma_vv(s_next[b], kf[gi % KA], qf[ks]);
+            if constexpr (gi + KA < NS) kf[gi % KA] = k_frag(std::integral_constant<int, gi + KA>{});
+        }
+        constexpr int n_done = started(gi), n_new = started(gi + 1) - n_done, n_prev = started(gi - 1),
+                      n_prev2 = started(gi - 2);
+        static_for<n_new>([&](auto jc) {
+            constexpr int e = n_done + decltype(jc)::value;
+            s_cur[e / 16][e % 16] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e / 16][e % 16], c, nm));
+        });
+        static_for<n_done - n_prev>([&](auto jc) {
+            constexpr int e = n_prev + decltype(jc)::value;
+            sum += s_cur[e / 16][e % 16];
+        });
+        static_for<n_prev / 2 - n_prev2 / 2>([&](auto jc) { convert_pair(std::integral_constant<int, n_prev2 / 2 + decltype(jc)::value>{}); });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NE - started(NS - 1)>([&](auto jc) {
+        constexpr int e = started(NS - 1) + decltype(jc)::value;
+        sum += s_cur[e / 16][e % 16];
+    });
+    static_for<NE / 2 - started(NS - 2) / 2>([&](auto jc) { convert_pair(std::integral_constant<int, started(NS - 2) / 2 + decltype(jc)::value>{}); });
+    l_run += sum;
+#pragma unroll
+    for (int j = 0; j < 2 * KB; ++j) pf[j] = __builtin_bit_cast(half8, pw[j]);
+    // pinned here (the optimiser would sink the vector side into the consuming block), with the wait states a
+    // vector write needs before an MFMA may read the register
+#pragma unroll
+    for (int j = 0; j < 2 * KB; ++j) asm volatile("s_nop 4" : "+v"(pf[j]));
+    asm volatile("" : "+v"(l_run));
+}
+
+// Block 2 of a step:
+//   matrix pipe   O^T += V(t)^T.P(t)^T                    (NP = 2 KB * D/32 MFMAs into a[0..], V^T fragments read VA ahead)
+//   vector ALU    row max of S_next (from gap 3 on: the last MFMA that wrote S_next is three MFMAs back by then)
+template <int D, int KB, bool NEXT>
+__device__ __forceinline__ void hd_block2(const char* vb, const LaneGeomD<D>& g, const half8 (&pf)[2 * KB],
+                                          const f32x16 (&s_next)[KB], float c, float& mx_next) {
+    using HD = HeadDim<D>;
+    constexpr int NP = 2 * KB * HD::kBlocks, VA = 4, NM = 8 * KB;  // NM: links of the max3 chain
+    half8 vf[VA];
+    static_for<VA>([&](auto ic) { vf[decltype(ic)::value] = hd_read_v<D, KB>(vb, g, decltype(ic)::value); });
+    float a = 0.0f;
+    static_for<NP>([&](auto ic) {
+        constexpr int gi = decltype(ic)::value, kk = gi / HD::kBlocks, db = gi % HD::kBlocks;
+        mfma_acc<16 * db>(vf[gi % VA], pf[kk]);
+        if constexpr (gi + VA < NP) vf[gi % VA] = hd_read_v<D, KB>(vb, g, gi + VA);
+        if constexpr (NEXT && gi >= 3) {
+            // links [lo, hi) of the chain in this gap
+            constexpr int lo = (gi - 3) * NM / (NP - 3), hi = (gi - 2) * NM / (NP - 3);
+            static_for<hi - lo>([&](auto jc) {
+                constexpr int j = lo + decltype(jc)::value, b = (2 * j) / 16, e = (2 * j) % 16;
+                if constexpr (j == 0)
+                    a = fmaxf(s_next[b][e], s_next[b][e + 1]);
+                else
+                    a = fmaxf(fmaxf(a, s_next[b][e]), s_next[b][e + 1]);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (NEXT) mx_next = half_wave_max(a) * c;
+}
+
+template <int D>
+__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_kernel(const FwdParams p) {
+    using HD = HeadDim<D>;
+    using CFG = HdCfg<D>;
+    constexpr int NWAVES = CFG::kWaves, TK = CFG::kTk, STAGES = CFG::kStages, KB = TK / 32;
+    constexpr int QB = NWAVES * kRowsPerWave;
+    constexpr int kTile = TK * HD::kRow;             // bytes of a K (or V) tile: 16 KiB
+    constexpr int kStage = 2 * kTile;                // K tile, then V tile
+    constexpr int kPieces = kTile / 1024;            // 1 KiB DMA pieces per tile: 16
+    constexpr int PPW = kPieces / NWAVES;            // pieces of each tile this wave moves
+    constexpr int kRowsPerPiece = 1024 / HD::kRow;   // 8 (D = 64) or 2 (D = 256)
+    static_assert(kTile == 16384 && PPW >= 1 && PPW * NWAVES == kPieces, "tile geometry");
+
+    __shared__ __attribute__((aligned(1024))) char ring[STAGES * kStage];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LaneGeomD<D> g = make_lane_geom_d<D>(lane);
+
+    int head, qb;
+    decode_item(p, (int)blockIdx.x, head, qb);
+    const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
+    const bool wave_valid = q_row0 < p.lq;              // a wave past the last row computes along on row block 0
+    const size_t srow = (size_t)head * p.lq + (wave_valid ? q_row0 : 0) + g.r;
+    const int n_tiles = p.lk / TK;
+    const float c = p.scale_log2e;
+
+    // ---- DMA geometry: this wave moves pieces PPW*wave .. PPW*wave + PPW - 1 of the K tile and of the V tile, i.e.
+    //      rows kRowsPerPiece * (PPW*wave + j) + rip.  Lane l fills slot l % chunks of row rip = l / chunks with the
+    //      source chunk the image's swizzle maps there.  Consecutive pieces are 1 KiB apart on both sides.
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
+    const int d_rip = lane / HD::kChunks, d_slot = lane % HD::kChunks;
+    unsigned d_koff[PPW], d_voff[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = kRowsPerPiece * (PPW * wave + j) + d_rip;   // row of the tile (piece j's share added by the offset)
+        const unsigned rowoff = (unsigned)((kRowsPerPiece * PPW * wave + d_rip) * HD::kRow);
+        d_koff[j] = rowoff + (unsigned)((d_slot ^ (row & HD::kKMask)) << 4);
+        d_voff[j] = rowoff + (unsigned)((d_slot ^ ((row & HD::kVMask) << 2)) << 4);
+    }
+    const unsigned d_lds = ring_lds + (unsigned)(PPW * wave) * 1024u;
+    const half_t* kh = p.k + (size_t)head * p.lk * D;
+    const half_t* vh = p.v + (size_t)head * p.lk * D;
+    auto dma_tile = [&](int tile, int stage) {
+        const half_t* kt = kh + (size_t)tile * TK * D;
+        const half_t* vt = vh + (size_t)tile * TK * D;
+        const unsigned l_ = d_lds + (unsigned)stage * (unsigned)kStage;
+        dma_set_base(l_);
+        static_for<PPW>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            dma_piece_at<1024 * j>(kt, d_koff[j]);
+        });
+        dma_set_base(l_ + (unsigned)kTile);
+        static_for<PPW>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            dma_piece_at<1024 * j>(vt, d_voff[j]);
+        });
+    };
+
+    // ---- prologue: tiles 0 and 1 on their way, Q fragments from global memory
+    dma_tile(0, 0);
+    if (n_tiles > 1) dma_tile(1, 1);
+    half8 qf[HD::kSteps];
+    {
+        const half_t* qr = p.q + srow * D + g.hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < HD::kSteps; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qr + ks * 16);
+    }
+    float l_run = 0.0f;
+    wait_all_vmem();
+    __syncthreads();
+    acc_reserve();
+    static_for<HD::kBlocks>([&](auto ic) { acc_zero16<16 * decltype(ic)::value>(); });
+
+    // scores of tile 0 and their row max: the first reference point
+    f32x16 s_cur[KB], s_next[KB];
+    hd_scores<D, KB>(ring, g, qf, s_cur);
+    float m_run = hd_row_max<KB>(s_cur, c);
+
+    int st = 0;  // stage of tile t
+    for (int t = 0; t < n_tiles; ++t) {
+        const int st1 = (st + 1 == STAGES) ? 0 : st + 1, st2 = (st1 + 1 == STAGES) ? 0 : st1 + 1;
+        const bool more = t + 1 < n_tiles;
+        if (t + 2 < n_tiles) dma_tile(t + 2, st2);  // into the stage tile t-1 occupied (its last reader passed the barrier)
+        half8 pf[2 * KB];
+        float mx = m_run;
+        if (__builtin_expect(more, 1)) {
+            hd_block1<D, KB, true>(ring + st1 * kStage, g, qf, s_next, s_cur, c, m_run, l_run, pf);
+            hd_block2<D, KB, true>(ring + st * kStage + kTile, g, pf, s_next, c, mx);
+            if (__builtin_expect(!__all(mx - m_run <= kRescaleSlack), 0)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+                acc_scale_n<0, 16 * HD::kBlocks>(alpha);
+            }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) s_cur[b] = s_next[b];
+        } else {
+            hd_block1<D, KB, false>(ring, g, qf, s_next, s_cur, c, m_run, l_run, pf);
+            hd_block2<D, KB, false>(ring + st * kStage + kTile, g, pf, s_next, c, mx);
+        }
+        wait_all_vmem();  // this wave's share of tile t+2 has landed
+        __syncthreads();
+        st = st1;
+    }
+
+    // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r in a[16db + 4g4 ..]
+    const float l_tot = half_wave_sum(l_run);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    acc_fence();
+    if (wave_valid) {
+        half_t* og = p.o + srow * D;
+        static_for<HD::kBlocks * 4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, db = i / 4, g4 = i % 4;
+            f32x4 v;
+            v[0] = acc_get<16 * db + 4 * g4 + 0>() * inv;
+            v[1] = acc_get<16 * db + 4 * g4 + 1>() * inv;
+            v[2] = acc_get<16 * db + 4 * g4 + 2>() * inv;
+            v[3] = acc_get<16 * db + 4 * g4 + 3>() * inv;
+            *reinterpret_cast<half4*>(og + 32 * db + 8 * g4 + 4 * g.hh) = __builtin_convertvector(v, half4);
+        });
+    }
+}
+
+}  // namespace fa

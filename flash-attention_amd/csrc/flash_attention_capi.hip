@@ -19,6 +19,7 @@
 #include "fa_fwd_ring_kernel.hpp"
 #include "fa_fwd_w64_kernel.hpp"
 #include "fa_fwd_general_kernel.hpp"
+#include "fa_fwd_hd_kernel.hpp"
 
 namespace {
 
@@ -47,6 +48,7 @@ int fail(int code, const char* fmt, const char* detail = "") {
 //   FA_MASKED_W64=1 / 0  masked forms of that kernel wherever they can run / nowhere (default: where measured faster)
 //   FA_BLOCK_TUNED=0     fa_forward_block_general keeps every block on the general kernel
 //   FA_SPLIT=0 / n       never split an item's keys over workgroups / over n of them (default: by the cost model)
+//   FA_HD=0              head dims 64 / 256 stay on the general kernel
 //   FA_RESERVED_CUS=k    initial value of fa_set_reserved_cus()
 //   FA_NWAVES=4, FA_RING=0   (builds with -DFA_AB_KERNELS only) the register-staged kernels kept for comparisons
 struct Switches {
@@ -57,6 +59,7 @@ struct Switches {
     int masked_w64 = -1;  // -1: the library's own choice
     bool block_tuned = true;
     int split = -1;  // -1: the cost model's choice
+    bool hd = true, hd64 = false;
 };
 std::atomic<const Switches*> g_switches{nullptr};
 std::once_flag g_switches_once;
@@ -79,6 +82,7 @@ const Switches* read_switches() {
     if (geti("FA_MASKED_W64", x)) sw->masked_w64 = x != 0;
     if (geti("FA_BLOCK_TUNED", x)) sw->block_tuned = x != 0;
     if (geti("FA_SPLIT", x) && x >= 0) sw->split = x;
+    if (geti("FA_HD", x)) sw->hd = x != 0, sw->hd64 = x == 2;
     if (geti("FA_RESERVED_CUS", x) && x >= 0) g_reserved_cus.store(x, std::memory_order_relaxed);
     return sw;
 }
@@ -364,6 +368,27 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
     return FA_OK;
 }
 
+// Head dims 64 and 256 in whole tiles without a mask: fa_fwd_hd_kernel<D> (FA_HD=0 keeps them on the general kernel).
+bool hd_kernel_takes(int flags, int D, int lq, int lk) {
+    if (flags != 0 || !switches().hd) return false;
+    if (D == 256) return lq % 64 == 0 && lk % 64 == 0;
+    // (D = 64 runs on this kernel only when forced, FA_HD=2: so far it is slower there than on the general kernel)
+    if (D == 64) return switches().hd64 && lq % 64 == 0 && lk % 128 == 0;
+    return false;
+}
+template <int D>
+int launch_hd(const fa::FwdParams& base, hipStream_t stream) {
+    fa::FwdParams p = base;
+    constexpr int kBlockRows = fa::HdCfg<D>::kWaves * fa::kRowsPerWave;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.q_blocks = (p.lq + kBlockRows - 1) / kBlockRows;
+    const long items = (long)p.bh * p.q_blocks;
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
+    hipLaunchKernelGGL(fa::fa_fwd_hd_kernel<D>, dim3((unsigned)items), dim3(fa::HdCfg<D>::kWaves * 64), 0, stream, p);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+
 // The masked forms of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
 // that are not whole tiles; they need Lq >= 64 (a wave's rows) and three tiles of keys.  Against the general
 // kernel (128-row workgroups) they lose where the last 256-row query block is at most half full and the
@@ -543,6 +568,7 @@ const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
         p.lq = lq, p.lk = lk, p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
         return masked_w64_name(p);
     }
+    if (hd_kernel_takes(flags, D, lq, lk)) return D == 64 ? "fa::fa_fwd_hd_kernel<64>" : "fa::fa_fwd_hd_kernel<256>";
     return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
 }
 
@@ -610,6 +636,9 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     }
     if (masked_on_w64(flags, D, Lq, Lk))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_masked(p, stream); });
+    if (hd_kernel_takes(flags, D, Lq, Lk))
+        return timed_launch(stream, elapsed_ms,
+                            [&]() -> int { return D == 64 ? launch_hd<64>(p, stream) : launch_hd<256>(p, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 

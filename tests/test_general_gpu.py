@@ -579,3 +579,55 @@ def test_padded_batch_only_key_lengths_given(fa, oracle, dev):
     o2 = fa.attention_varlen(q, k, v)
     torch.cuda.synchronize()
     assert torch.equal(o2, fa.attention_general(q, k, v))
+
+
+# ------------------------------------------------------------------------------------------------
+# head dims 64 and 256 in whole tiles: fa_fwd_hd_kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,Lq,Lk", [
+    (256, 64, 64), (256, 128, 192), (256, 192, 64), (256, 320, 448), (256, 1024, 1024), (256, 512, 2048),
+    (64, 64, 128), (64, 128, 256), (64, 192, 384), (64, 320, 128), (64, 1024, 1024), (64, 512, 2048),
+])
+def test_other_head_dims_whole_tiles(fa, oracle, dev, D, Lq, Lk, fa_env):
+    """D = 64 / 256 with whole tiles run on fa_fwd_hd_kernel<D> (one to many K/V tiles per item, partly filled
+    last query blocks, Lq != Lk), inputs followed by NaN and the output by a sentinel; whole tensors against the
+    oracle and, within rounding, against the general kernel."""
+    import torch
+
+    fa_env(FA_HD="2")  # (2: D = 64 as well, which the launcher does not send there by itself yet)
+    assert fa.lib().fa_kernel_name_general(Lq, Lk, D, 0) == f"fa::fa_fwd_hd_kernel<{D}>".encode()
+    rng = np.random.default_rng(D + Lq + Lk)
+    Q = rng.standard_normal((2, 3, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((2, 3, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((2, 3, Lk, D), dtype=np.float32).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V)
+    st = oracle.BlockState(2, 3, Lq, D)
+    oracle.block_update(st, Q, K, V)
+    gate(oracle, oracle.block_finalize(st), O, f"D={D} Lq={Lq} Lk={Lk}")
+    fa_env(FA_HD="0")
+    assert fa.lib().fa_kernel_name_general(Lq, Lk, D, 0) == f"fa::fa_fwd_general_kernel<{D}>".encode()
+    O2 = run_general(fa, dev, Q, K, V)
+    assert np.abs(O.astype(np.float32) - O2.astype(np.float32)).max() <= 1e-3
+
+
+@pytest.mark.parametrize("D", [64, 256])
+def test_other_head_dims_rescale_and_repeat(fa, oracle, dev, D, fa_env):
+    """A dominating key in every 128-key stretch, growing along the sequence: the running reference moves (the
+    accumulator rescale runs) on most tiles; several heads so that many workgroups run; results repeat bit for bit."""
+    import torch
+
+    fa_env(FA_HD="2")
+    rng = np.random.default_rng(D)
+    shape = (1, 20, 1024, D)
+    Q = (rng.standard_normal(shape) * 1.5).astype(np.float16)
+    K = (rng.standard_normal(shape) * 1.5).astype(np.float16)
+    V = (rng.standard_normal(shape) * 0.5).astype(np.float16)  # (|O| stays below 2, where fp16 neighbours are 1e-3 apart)
+    for t in range(8):
+        for row in (3, 40, 70, 200, 255, 300, 511, 1000):
+            K[:, :, 128 * t + (row % 128), :] = (Q[:, :, row, :].astype(np.float32) * (0.1 + 0.06 * t)).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o1 = fa.attention_general(q, k, v).clone()
+    o2 = fa.attention_general(q, k, v)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    gate(oracle, oracle.attention_cpu(Q, K, V), o1.cpu().numpy(), f"D={D} spiked")
