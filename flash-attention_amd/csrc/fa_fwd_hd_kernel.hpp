@@ -7,15 +7,19 @@
 // from the score registers into O^T += V^T.P^T, K/V tiles travelling global -> LDS by DMA (global_load_lds_dwordx4,
 // swizzle applied on the source side, hidden from the compiler and awaited by hand) into a ring of stages, one
 // barrier per step, the deferred rescale.  What differs:
-//   * a stage is one K tile and one V tile of TK keys, 16 KiB each whatever the head dim: TK = 128 keys for D = 64,
-//     32 keys for D = 256;
+//   * a stage is one K tile and one V tile of TK keys: 32 keys (16 KiB a tile) for D = 256, 64 keys (8 KiB) for D = 64;
 //   * one workgroup per (head, query block), not persistent: Q fragments come straight from global memory, the
 //     output goes straight back (these shapes are long enough for the item boundary not to matter);
 //   * the two matrix products of a tile are software-pipelined INSIDE a wave: while the matrix pipe computes the
 //     next tile's scores, the vector ALU turns the current tile's scores into probabilities; while it multiplies
 //     those with V, the vector ALU takes the next scores' row max.  D = 256 needs this because its 128
-//     accumulator registers per 32 rows leave room for one wave per SIMD only (no second wave to overlap with);
-//     the instruction mix is left to the compiler's scheduler, guided by sched_group_barrier.
+//     accumulator registers per 32 rows leave room for one wave per SIMD only (no second wave to overlap with).
+//     Both blocks of a step are written out gap by gap (one MFMA, then that gap's share of the vector work and of
+//     the operand reads, sched_barrier(0)), as the phases of fa_fwd_w64_kernel are.
+// Tried for D = 64, where the vector ALU binds, and measured slower: the packed forms v_pk_fma_f32 / v_pk_add_f32
+// (-5 %, D = 256: -10 %), 128-key tiles (-25 %), eight waves per workgroup (-10 %), the row sums through one more
+// MFMA per 16 keys (ones x P^T) instead of one addition per score (-7 % with the 48 accumulator registers it
+// needs at two waves per SIMD; with the architectural registers capped for three the compiler spilled into them).
 #pragma once
 #include "fa_fwd_general_kernel.hpp"
 #include "fa_fwd_ring_kernel.hpp"
@@ -31,13 +35,22 @@ struct HdCfg<256> {
     static constexpr int kTk = 32;      // keys per tile
     static constexpr int kStages = 3;   // 3 x 32 KiB
     static constexpr int kOcc = 1;
+    static constexpr int kAhead = 4;    // operand fragments read this many MFMAs ahead of their use
 };
+#ifndef FA_HD64_WAVES
+#define FA_HD64_WAVES 4
+#define FA_HD64_TK 64
+#endif
 template <>
 struct HdCfg<64> {
-    static constexpr int kWaves = 4;    // as above; the vector ALU binds here (one exponential per 256 FLOP)
-    static constexpr int kTk = 128;
+    static constexpr int kWaves = FA_HD64_WAVES;  // the vector ALU binds here (one exponential per 256 FLOP)
+    static constexpr int kTk = FA_HD64_TK;
     static constexpr int kStages = 3;
-    static constexpr int kOcc = 1;
+    static constexpr int kOcc = FA_HD64_WAVES / 4;
+#ifndef FA_HD64_AHEAD
+#define FA_HD64_AHEAD 2
+#endif
+    static constexpr int kAhead = FA_HD64_AHEAD;
 };
 
 // All MFMAs are inline asm with explicit register files, as in fa_fwd_w64_kernel: the O^T accumulator lives in
@@ -52,6 +65,12 @@ __device__ __forceinline__ void mfma_vv(f32x16& d, const half8& a, const half8& 
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
+// Makes the kernel descriptor allocate a[0:31] only (D = 64: the whole accumulator).  With several waves per SIMD a
+// wave's architectural and accumulator registers come out of one budget: 128 + 32 lets three workgroups share a CU.
+__device__ __forceinline__ void acc_reserve32() {
+    asm volatile("" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15",
+                 "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+}
 // a[LO : LO+15] = 0 through the matrix pipe; a[BASE : BASE+N-1] *= alpha through the vector ALU (rare: the rescale).
 template <int LO>
 __device__ __forceinline__ void acc_zero16() {
@@ -111,14 +130,16 @@ __device__ __forceinline__ half8 hd_read_v(const char* vb, const LaneGeomD<D>& g
 //   matrix pipe   S_next = K(t+1).Q^T                     (NS = KB * D/16 MFMAs, K fragments read KA ahead)
 //   vector ALU    p = exp2(S_cur c - m), row sum, P^T     (16 KB elements spread over the gaps; an element is summed
 //                                                          one gap after its exponential, a pair rounded to fp16
-//                                                          one gap after that)
+//                                                          one gap after that; plain fp32 instructions: the packed
+//                                                          forms v_pk_fma_f32 / v_pk_add_f32 measured 5-10 % slower
+//                                                          beside MFMAs)
 // With NEXT = false (the last tile) only the vector side runs.
 template <int D, int KB, bool NEXT>
 __device__ __forceinline__ void hd_block1(const char* kb, const LaneGeomD<D>& g, const half8 (&qf)[HeadDim<D>::kSteps],
                                           f32x16 (&s_next)[KB], f32x16 (&s_cur)[KB], float c, float m_run, float& l_run,
                                           half8 (&pf)[2 * KB]) {
     using HD = HeadDim<D>;
-    constexpr int NS = HD::kSteps * KB, NE = 16 * KB, KA = 4;
+    constexpr int NS = HD::kSteps * KB, NE = 16 * KB, KA = HdCfg<D>::kAhead;
     const float nm = -m_run;
     float sum = 0.0f;
     u32x4 pw[2 * KB] = {};
@@ -181,7 +202,8 @@ template <int D, int KB, bool NEXT>
 __device__ __forceinline__ void hd_block2(const char* vb, const LaneGeomD<D>& g, const half8 (&pf)[2 * KB],
                                           const f32x16 (&s_next)[KB], float c, float& mx_next) {
     using HD = HeadDim<D>;
-    constexpr int NP = 2 * KB * HD::kBlocks, VA = 4, NM = 8 * KB;  // NM: links of the max3 chain
+    constexpr int NP = 2 * KB * HD::kBlocks, VA = HdCfg<D>::kAhead;
+    constexpr int NM = 8 * KB;  // links of the max3 chain
     half8 vf[VA];
     static_for<VA>([&](auto ic) { vf[decltype(ic)::value] = hd_read_v<D, KB>(vb, g, decltype(ic)::value); });
     float a = 0.0f;
@@ -193,8 +215,8 @@ __device__ __forceinline__ void hd_block2(const char* vb, const LaneGeomD<D>& g,
             // links [lo, hi) of the chain in this gap
             constexpr int lo = (gi - 3) * NM / (NP - 3), hi = (gi - 2) * NM / (NP - 3);
             static_for<hi - lo>([&](auto jc) {
-                constexpr int j = lo + decltype(jc)::value, b = (2 * j) / 16, e = (2 * j) % 16;
-                if constexpr (j == 0)
+                constexpr int jl = lo + decltype(jc)::value, b = (2 * jl) / 16, e = (2 * jl) % 16;
+                if constexpr (jl == 0)
                     a = fmaxf(s_next[b][e], s_next[b][e + 1]);
                 else
                     a = fmaxf(fmaxf(a, s_next[b][e]), s_next[b][e + 1]);
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     constexpr int kPieces = kTile / 1024;            // 1 KiB DMA pieces per tile: 16
     constexpr int PPW = kPieces / NWAVES;            // pieces of each tile this wave moves
     constexpr int kRowsPerPiece = 1024 / HD::kRow;   // 8 (D = 64) or 2 (D = 256)
-    static_assert(kTile == 16384 && PPW >= 1 && PPW * NWAVES == kPieces, "tile geometry");
+    static_assert(PPW >= 1 && PPW * NWAVES == kPieces, "tile geometry");
 
     __shared__ __attribute__((aligned(1024))) char ring[STAGES * kStage];
 
@@ -277,7 +299,10 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     float l_run = 0.0f;
     wait_all_vmem();
     __syncthreads();
-    acc_reserve();
+    if constexpr (D == 64)
+        acc_reserve32();
+    else
+        acc_reserve();
     static_for<HD::kBlocks>([&](auto ic) { acc_zero16<16 * decltype(ic)::value>(); });
 
     // scores of tile 0 and their row max: the first reference point
@@ -314,9 +339,9 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     }
 
     // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r in a[16db + 4g4 ..]
+    acc_fence();
     const float l_tot = half_wave_sum(l_run);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-    acc_fence();
     if (wave_valid) {
         half_t* og = p.o + srow * D;
         static_for<HD::kBlocks * 4>([&](auto ic) {

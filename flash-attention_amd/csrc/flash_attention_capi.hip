@@ -59,7 +59,7 @@ struct Switches {
     int masked_w64 = -1;  // -1: the library's own choice
     bool block_tuned = true;
     int split = -1;  // -1: the cost model's choice
-    bool hd = true, hd64 = false;
+    bool hd = true;
 };
 std::atomic<const Switches*> g_switches{nullptr};
 std::once_flag g_switches_once;
@@ -82,7 +82,7 @@ const Switches* read_switches() {
     if (geti("FA_MASKED_W64", x)) sw->masked_w64 = x != 0;
     if (geti("FA_BLOCK_TUNED", x)) sw->block_tuned = x != 0;
     if (geti("FA_SPLIT", x) && x >= 0) sw->split = x;
-    if (geti("FA_HD", x)) sw->hd = x != 0, sw->hd64 = x == 2;
+    if (geti("FA_HD", x)) sw->hd = x != 0;
     if (geti("FA_RESERVED_CUS", x) && x >= 0) g_reserved_cus.store(x, std::memory_order_relaxed);
     return sw;
 }
@@ -372,8 +372,7 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
 bool hd_kernel_takes(int flags, int D, int lq, int lk) {
     if (flags != 0 || !switches().hd) return false;
     if (D == 256) return lq % 64 == 0 && lk % 64 == 0;
-    // (D = 64 runs on this kernel only when forced, FA_HD=2: so far it is slower there than on the general kernel)
-    if (D == 64) return switches().hd64 && lq % 64 == 0 && lk % 128 == 0;
+    if (D == 64) return lq % 64 == 0 && lk % fa::HdCfg<64>::kTk == 0;
     return false;
 }
 template <int D>

@@ -594,7 +594,7 @@ def test_other_head_dims_whole_tiles(fa, oracle, dev, D, Lq, Lk, fa_env):
     oracle and, within rounding, against the general kernel."""
     import torch
 
-    fa_env(FA_HD="2")  # (2: D = 64 as well, which the launcher does not send there by itself yet)
+    fa_env(FA_HD=None)
     assert fa.lib().fa_kernel_name_general(Lq, Lk, D, 0) == f"fa::fa_fwd_hd_kernel<{D}>".encode()
     rng = np.random.default_rng(D + Lq + Lk)
     Q = rng.standard_normal((2, 3, Lq, D), dtype=np.float32).astype(np.float16)
@@ -616,7 +616,7 @@ def test_other_head_dims_rescale_and_repeat(fa, oracle, dev, D, fa_env):
     accumulator rescale runs) on most tiles; several heads so that many workgroups run; results repeat bit for bit."""
     import torch
 
-    fa_env(FA_HD="2")
+    fa_env(FA_HD=None)
     rng = np.random.default_rng(D)
     shape = (1, 20, 1024, D)
     Q = (rng.standard_normal(shape) * 1.5).astype(np.float16)
