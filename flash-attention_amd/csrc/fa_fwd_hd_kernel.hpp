@@ -33,9 +33,15 @@ template <>
 struct HdCfg<256> {
     static constexpr int kWaves = 4;    // 32 rows each: 128-row query blocks, one wave per SIMD
     static constexpr int kTk = 32;      // keys per tile
-    static constexpr int kStages = 3;   // 3 x 32 KiB
+#ifndef FA_HD256_STAGES
+#define FA_HD256_STAGES 4
+#endif
+    static constexpr int kStages = FA_HD256_STAGES;  // x 32 KiB: the tile sent for in step t is awaited at the end of step t + kStages - 3
     static constexpr int kOcc = 1;
-    static constexpr int kAhead = 4;    // operand fragments read this many MFMAs ahead of their use
+#ifndef FA_HD256_AHEAD
+#define FA_HD256_AHEAD 4
+#endif
+    static constexpr int kAhead = FA_HD256_AHEAD;  // operand fragments read this many MFMAs ahead of their use
 };
 #ifndef FA_HD64_WAVES
 #define FA_HD64_WAVES 4
@@ -134,10 +140,12 @@ __device__ __forceinline__ half8 hd_read_v(const char* vb, const LaneGeomD<D>& g
 //                                                          forms v_pk_fma_f32 / v_pk_add_f32 measured 5-10 % slower
 //                                                          beside MFMAs)
 // With NEXT = false (the last tile) only the vector side runs.
-template <int D, int KB, bool NEXT>
+//   tile transfer dma(j), j = 0 .. NDMA-1: this wave's DMA pieces of the step, one every NS / NDMA gaps (issued in one
+//                 burst they stall the wave on the memory pipe's issue queue: measured 19 % of the D = 256 step)
+template <int D, int KB, bool NEXT, int NDMA, typename DMA>
 __device__ __forceinline__ void hd_block1(const char* kb, const LaneGeomD<D>& g, const half8 (&qf)[HeadDim<D>::kSteps],
                                           f32x16 (&s_next)[KB], f32x16 (&s_cur)[KB], float c, float m_run, float& l_run,
-                                          half8 (&pf)[2 * KB]) {
+                                          half8 (&pf)[2 * KB], DMA&& dma) {
     using HD = HeadDim<D>;
     constexpr int NS = HD::kSteps * KB, NE = 16 * KB, KA = HdCfg<D>::kAhead;
     const float nm = -m_run;
@@ -166,13 +174,17 @@ __device__ __forceinline__ void hd_block1(const char* kb, const LaneGeomD<D>& g,
             else
                 mfma_vv(s_next[b], kf[gi % KA], qf[ks]);
             if constexpr (gi + KA < NS) kf[gi % KA] = k_frag(std::integral_constant<int, gi + KA>{});
+            constexpr int every = NS / NDMA;
+            if constexpr (gi % every == every - 1) dma(std::integral_constant<int, gi / every>{});
         }
         constexpr int n_done = started(gi), n_new = started(gi + 1) - n_done, n_prev = started(gi - 1),
                       n_prev2 = started(gi - 2);
+#ifndef FA_HD_ABLATE_VEC
         static_for<n_new>([&](auto jc) {
             constexpr int e = n_done + decltype(jc)::value;
             s_cur[e / 16][e % 16] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e / 16][e % 16], c, nm));
         });
+#endif
         static_for<n_done - n_prev>([&](auto jc) {
             constexpr int e = n_prev + decltype(jc)::value;
             sum += s_cur[e / 16][e % 16];
@@ -211,7 +223,11 @@ __device__ __forceinline__ void hd_block2(const char* vb, const LaneGeomD<D>& g,
         constexpr int gi = decltype(ic)::value, kk = gi / HD::kBlocks, db = gi % HD::kBlocks;
         mfma_acc<16 * db>(vf[gi % VA], pf[kk]);
         if constexpr (gi + VA < NP) vf[gi % VA] = hd_read_v<D, KB>(vb, g, gi + VA);
+#ifdef FA_HD_ABLATE_MAX
+        if constexpr (false) {
+#else
         if constexpr (NEXT && gi >= 3) {
+#endif
             // links [lo, hi) of the chain in this gap
             constexpr int lo = (gi - 3) * NM / (NP - 3), hi = (gi - 2) * NM / (NP - 3);
             static_for<hi - lo>([&](auto jc) {
@@ -287,9 +303,13 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
         });
     };
 
-    // ---- prologue: tiles 0 and 1 on their way, Q fragments from global memory
-    dma_tile(0, 0);
-    if (n_tiles > 1) dma_tile(1, 1);
+    // ---- prologue: the first PF = STAGES - 1 tiles on their way, Q fragments from global memory
+    constexpr int PF = STAGES - 1;
+    static_assert(PF >= 2 && (PF - 2) * 2 * PPW < 64, "look-ahead against the load counter's width");
+    static_for<PF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i == 0 || i < n_tiles) dma_tile(i, i);
+    });
     half8 qf[HD::kSteps];
     {
         const half_t* qr = p.q + srow * D + g.hh * 8;
@@ -312,13 +332,31 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
 
     int st = 0;  // stage of tile t
     for (int t = 0; t < n_tiles; ++t) {
-        const int st1 = (st + 1 == STAGES) ? 0 : st + 1, st2 = (st1 + 1 == STAGES) ? 0 : st1 + 1;
+        const int st1 = (st + 1 == STAGES) ? 0 : st + 1, st2 = (st == 0) ? STAGES - 1 : st - 1;
         const bool more = t + 1 < n_tiles;
-        if (t + 2 < n_tiles) dma_tile(t + 2, st2);  // into the stage tile t-1 occupied (its last reader passed the barrier)
+        // this step's transfer: tile t+PF (past the end: the last tile once more, into a stage nobody reads any more),
+        // into the stage tile t-1 occupied (its last reader has passed the barrier); issued piece by piece inside block 1
+        const int t2 = t + PF < n_tiles ? t + PF : n_tiles - 1;
+        const half_t* kt2 = kh + (size_t)t2 * TK * D;
+        const half_t* vt2 = vh + (size_t)t2 * TK * D;
+        const unsigned l2 = d_lds + (unsigned)st2 * (unsigned)kStage;
+        auto dma_step = [&](auto jc) {
+#ifndef FA_HD_ABLATE_DMA  // (the FA_HD_ABLATE_* builds are timing experiments: wrong results)
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j == 0) dma_set_base(l2);
+            if constexpr (j == PPW) dma_set_base(l2 + (unsigned)kTile);
+            if constexpr (j < PPW)
+                dma_piece_at<1024 * j>(kt2, d_koff[j]);
+            else
+                dma_piece_at<1024 * (j - PPW)>(vt2, d_voff[j - PPW]);
+#endif
+        };
+        auto dma_none = [&](auto) {};
+#define FA_HD_KEEP_SEMICOLON  // into the stage tile t-1 occupied (its last reader passed the barrier)
         half8 pf[2 * KB];
         float mx = m_run;
         if (__builtin_expect(more, 1)) {
-            hd_block1<D, KB, true>(ring + st1 * kStage, g, qf, s_next, s_cur, c, m_run, l_run, pf);
+            hd_block1<D, KB, true, 2 * PPW>(ring + st1 * kStage, g, qf, s_next, s_cur, c, m_run, l_run, pf, dma_step);
             hd_block2<D, KB, true>(ring + st * kStage + kTile, g, pf, s_next, c, mx);
             if (__builtin_expect(!__all(mx - m_run <= kRescaleSlack), 0)) {
                 const float m_new = fmaxf(m_run, mx);
@@ -330,14 +368,19 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
 #pragma unroll
             for (int b = 0; b < KB; ++b) s_cur[b] = s_next[b];
         } else {
-            hd_block1<D, KB, false>(ring, g, qf, s_next, s_cur, c, m_run, l_run, pf);
+            hd_block1<D, KB, false, 2 * PPW>(ring, g, qf, s_next, s_cur, c, m_run, l_run, pf, dma_none);
             hd_block2<D, KB, false>(ring + st * kStage + kTile, g, pf, s_next, c, mx);
         }
-        wait_all_vmem();  // this wave's share of tile t+2 has landed
+#ifndef FA_HD_ABLATE_BARRIER
+        // this wave's share of tile t+2 has landed (the next step reads its K): it was sent for PF - 2 steps ago, and
+        // the pieces of the steps since stay in flight (loads complete in order)
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((PF - 2) * 2 * PPW) : "memory");
         __syncthreads();
+#endif
         st = st1;
     }
 
+    wait_all_vmem();  // (the last steps' redundant transfers must not outlive the workgroup's LDS)
     // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r in a[16db + 4g4 ..]
     acc_fence();
     const float l_tot = half_wave_sum(l_run);
