@@ -384,6 +384,15 @@ def device_info() -> dict:
     return {"compute_units": cus.value, "clock_khz": khz.value, "fp16_dense_peak_flops": peak.value}
 
 
+def mae_mre(ref32: np.ndarray, test16: np.ndarray):
+    """Mean absolute error and mean relative error over the reference's non-zero entries, the two figures
+    benchmarks/compare_impls.py:66-74 prints."""
+    a = np.asarray(ref32, dtype=np.float32).reshape(-1)
+    d = np.abs(a - np.asarray(test16).astype(np.float32).reshape(-1))
+    nz = a != 0
+    return float(d.mean()), (float((d[nz] / np.abs(a[nz])).mean()) if nz.any() else float("nan"))
+
+
 def attention_flops(B: int, H: int, L: int, D: int) -> float:
     """4*B*H*L^2*D (benchmark_tensor_flash_attention.cu:218)."""
     return 4.0 * B * H * float(L) * float(L) * D

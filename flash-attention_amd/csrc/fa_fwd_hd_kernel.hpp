@@ -330,16 +330,20 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     hd_scores<D, KB>(ring, g, qf, s_cur);
     float m_run = hd_row_max<KB>(s_cur, c);
 
-    int st = 0;  // stage of tile t
-    for (int t = 0; t < n_tiles; ++t) {
-        const int st1 = (st + 1 == STAGES) ? 0 : st + 1, st2 = (st == 0) ? STAGES - 1 : st - 1;
+    // One step per tile.  The loop below is STAGES copies of it, one per ring stage, so that every stage offset is a
+    // compile-time constant and the LDS reads take it as their immediate offset (with a run-time stage every read
+    // paid a vector instruction to form its address: 24 of about 160 per tile and wave at D = 64).  Tile t lives in
+    // stage t % STAGES.  Returns true after the last tile.
+    int t = 0;
+    auto step = [&](auto sc) -> bool {
+        constexpr int ST = decltype(sc)::value, ST1 = (ST + 1) % STAGES, ST2 = (ST + STAGES - 1) % STAGES;
         const bool more = t + 1 < n_tiles;
         // this step's transfer: tile t+PF (past the end: the last tile once more, into a stage nobody reads any more),
         // into the stage tile t-1 occupied (its last reader has passed the barrier); issued piece by piece inside block 1
         const int t2 = t + PF < n_tiles ? t + PF : n_tiles - 1;
         const half_t* kt2 = kh + (size_t)t2 * TK * D;
         const half_t* vt2 = vh + (size_t)t2 * TK * D;
-        const unsigned l2 = d_lds + (unsigned)st2 * (unsigned)kStage;
+        const unsigned l2 = d_lds + (unsigned)(ST2 * kStage);
         auto dma_step = [&](auto jc) {
 #ifndef FA_HD_ABLATE_DMA  // (the FA_HD_ABLATE_* builds are timing experiments: wrong results)
             constexpr int j = decltype(jc)::value;
@@ -352,12 +356,11 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
 #endif
         };
         auto dma_none = [&](auto) {};
-#define FA_HD_KEEP_SEMICOLON  // into the stage tile t-1 occupied (its last reader passed the barrier)
         half8 pf[2 * KB];
         float mx = m_run;
         if (__builtin_expect(more, 1)) {
-            hd_block1<D, KB, true, 2 * PPW>(ring + st1 * kStage, g, qf, s_next, s_cur, c, m_run, l_run, pf, dma_step);
-            hd_block2<D, KB, true>(ring + st * kStage + kTile, g, pf, s_next, c, mx);
+            hd_block1<D, KB, true, 2 * PPW>(ring + ST1 * kStage, g, qf, s_next, s_cur, c, m_run, l_run, pf, dma_step);
+            hd_block2<D, KB, true>(ring + ST * kStage + kTile, g, pf, s_next, c, mx);
             if (__builtin_expect(!__all(mx - m_run <= kRescaleSlack), 0)) {
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
             for (int b = 0; b < KB; ++b) s_cur[b] = s_next[b];
         } else {
             hd_block1<D, KB, false, 2 * PPW>(ring, g, qf, s_next, s_cur, c, m_run, l_run, pf, dma_none);
-            hd_block2<D, KB, false>(ring + st * kStage + kTile, g, pf, s_next, c, mx);
+            hd_block2<D, KB, false>(ring + ST * kStage + kTile, g, pf, s_next, c, mx);
+            return true;
         }
 #ifndef FA_HD_ABLATE_BARRIER
         // this wave's share of tile t+2 has landed (the next step reads its K): it was sent for PF - 2 steps ago, and
@@ -377,7 +381,17 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"((PF - 2) * 2 * PPW) : "memory");
         __syncthreads();
 #endif
-        st = st1;
+        ++t;
+        return false;
+    };
+    for (;;) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
+        if (step(std::integral_constant<int, 2>{})) break;
+        if constexpr (STAGES > 3)
+            if (step(std::integral_constant<int, 3>{})) break;
+        if constexpr (STAGES > 4)
+            if (step(std::integral_constant<int, 4>{})) break;
     }
 
     wait_all_vmem();  // (the last steps' redundant transfers must not outlive the workgroup's LDS)
