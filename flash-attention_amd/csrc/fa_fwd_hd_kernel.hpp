@@ -243,8 +243,32 @@ __device__ __forceinline__ void hd_block2(const char* vb, const LaneGeomD<D>& g,
     if constexpr (NEXT) mx_next = half_wave_max(a) * c;
 }
 
-template <int D>
-__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_kernel(const FwdParams p) {
+// Upper-bound mask on fresh scores, between the two blocks (or after the prologue's scores): element e of key block b
+// in lane (r, hh) is key 32 b + 8 (e >> 2) + (e & 3) + 4 hh of the tile; it stays iff that is <= thr + 4 hh, thr per
+// lane = (last key this query row may see) - (the tile's first key).  Masked scores become -inf: their exponential is 0
+// and they leave the row max alone.
+template <int KB>
+__device__ __forceinline__ void hd_mask_scores(f32x16 (&s)[KB], int thr_minus_4hh) {
+    const float ninf = -__builtin_inff();
+#pragma unroll
+    for (int b = 0; b < KB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int kc = 32 * b + 8 * (e >> 2) + (e & 3);
+            s[b][e] = kc > thr_minus_4hh ? ninf : s[b][e];
+        }
+}
+
+// MASKED = false: whole tiles, no mask (lq % 32 == 0, lk % TK == 0).  MASKED = true adds, outside the two blocks,
+//   * any lq >= 1: query rows past the end are computed on a copy of the last row and not stored;
+//   * any lk >= 0: the rows of the last tile that lie past the last key are fetched from the last key's row (finite
+//     data) and their scores masked; no keys at all gives O = 0;
+//   * the causal mask of attention_cpu (testing.cu:74-77: key j <= query i, both counted from the sequence's start): a
+//     workgroup stops at the tile that holds its last row's diagonal, the long query blocks are handed out first;
+//   * padded batches: per-sequence lengths q_len[b], k_len[b] (device arrays) in place of lq, lk, which stay the strides.
+// A tile that the diagonal or the sequence's end touches gets hd_mask_scores() in a cold branch between the blocks.
+template <int D, bool MASKED>
+__device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     using HD = HeadDim<D>;
     using CFG = HdCfg<D>;
     constexpr int NWAVES = CFG::kWaves, TK = CFG::kTk, STAGES = CFG::kStages, KB = TK / 32;
@@ -265,11 +289,42 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
 
     int head, qb;
     decode_item(p, (int)blockIdx.x, head, qb);
+    [[maybe_unused]] const bool causal = MASKED && (p.flags & kFlagCausal) != 0;
+    int lq_v = p.lq, lk_v = p.lk;  // this sequence's valid rows and keys
+    if constexpr (MASKED) {
+        if (causal) qb = p.q_blocks - 1 - qb;  // block qb costs qb + 1 units: the long ones first
+        if (p.q_len || p.k_len) {
+            const int batch = head / p.heads_per_batch;
+            if (p.q_len) lq_v = min(max(p.q_len[batch], 0), p.lq);
+            if (p.k_len) lk_v = min(max(p.k_len[batch], 0), p.lk);
+        }
+        if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
+    }
     const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
-    const bool wave_valid = q_row0 < p.lq;              // a wave past the last row computes along on row block 0
-    const size_t srow = (size_t)head * p.lq + (wave_valid ? q_row0 : 0) + g.r;
-    const int n_tiles = p.lk / TK;
+    const bool wave_valid = q_row0 < lq_v;              // a wave past the last row computes along and stores nothing
+    // this lane's query row: past the end, the last row (MASKED) or the block's first rows (whole tiles)
+    const int q_abs = MASKED ? min(q_row0 + g.r, lq_v - 1) : (wave_valid ? q_row0 : 0) + g.r;
+    const size_t srow = (size_t)head * p.lq + q_abs;
     const float c = p.scale_log2e;
+    int n_tiles = MASKED ? (lk_v + TK - 1) / TK : p.lk / TK;
+    [[maybe_unused]] const int last_key_tile = n_tiles - 1;          // the tile the sequence's end may cut
+    [[maybe_unused]] const bool ragged_end = MASKED && lk_v % TK != 0;
+    if constexpr (MASKED) {
+        if (causal) n_tiles = min(n_tiles, (min(qb * QB + QB, lq_v) + TK - 1) / TK);
+        if (n_tiles == 0) {  // no keys: O = 0
+            if (wave_valid && q_row0 + g.r < lq_v) {
+                half_t* og = p.o + srow * D;
+#pragma unroll
+                for (int i = 0; i < D / 4; i += 2) *reinterpret_cast<half4*>(og + 4 * (i + g.hh)) = half4{};
+            }
+            return;
+        }
+    }
+    // last key this lane's row may see, and whether tile `tile` needs the mask for this wave (wave-uniform)
+    [[maybe_unused]] const int key_limit = causal ? min(lk_v - 1, q_abs) : lk_v - 1;
+    [[maybe_unused]] auto needs_mask = [&](int tile) -> bool {
+        return (ragged_end && tile == last_key_tile) || (causal && tile * TK + TK - 1 > q_row0);
+    };
 
     // ---- DMA geometry: this wave moves pieces PPW*wave .. PPW*wave + PPW - 1 of the K tile and of the V tile, i.e.
     //      rows kRowsPerPiece * (PPW*wave + j) + rip.  Lane l fills slot l % chunks of row rip = l / chunks with the
@@ -287,19 +342,45 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     const unsigned d_lds = ring_lds + (unsigned)(PPW * wave) * 1024u;
     const half_t* kh = p.k + (size_t)head * p.lk * D;
     const half_t* vh = p.v + (size_t)head * p.lk * D;
+    // MASKED: the same offsets for the tile the sequence's end cuts, with every row past the last key replaced by the
+    // last key's row.  (The instruction's immediate offset 1024 j is added on both sides, so it is taken off here.)
+    [[maybe_unused]] unsigned d_koff_end[PPW], d_voff_end[PPW];
+    if constexpr (MASKED) {
+        const int rows_in_last = lk_v - last_key_tile * TK;  // 1 .. TK
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int row = kRowsPerPiece * (PPW * wave + j) + d_rip;
+            const int src = min(row, rows_in_last - 1);
+            // (src - row) * kRow <= 0: folded into the 64-bit base below, the 32-bit offset stays non-negative
+            d_koff_end[j] = (unsigned)(src * HD::kRow) + (unsigned)((d_slot ^ (row & HD::kKMask)) << 4);
+            d_voff_end[j] = (unsigned)(src * HD::kRow) + (unsigned)((d_slot ^ ((row & HD::kVMask) << 2)) << 4);
+        }
+    }
+    // One tile's transfer, all pieces at once (the prologue).  `cut`: the tile the sequence's end cuts.
     auto dma_tile = [&](int tile, int stage) {
         const half_t* kt = kh + (size_t)tile * TK * D;
         const half_t* vt = vh + (size_t)tile * TK * D;
         const unsigned l_ = d_lds + (unsigned)stage * (unsigned)kStage;
-        dma_set_base(l_);
+        const bool cut = ragged_end && tile == last_key_tile;
         static_for<PPW>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            dma_piece_at<1024 * j>(kt, d_koff[j]);
+            if (MASKED && cut) {
+                dma_set_base(l_ + 1024u * j);
+                dma_piece_at<0>(kt, d_koff_end[j]);
+            } else {
+                dma_set_base(l_);
+                dma_piece_at<1024 * j>(kt, d_koff[j]);
+            }
         });
-        dma_set_base(l_ + (unsigned)kTile);
         static_for<PPW>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            dma_piece_at<1024 * j>(vt, d_voff[j]);
+            if (MASKED && cut) {
+                dma_set_base(l_ + (unsigned)kTile + 1024u * j);
+                dma_piece_at<0>(vt, d_voff_end[j]);
+            } else {
+                dma_set_base(l_ + (unsigned)kTile);
+                dma_piece_at<1024 * j>(vt, d_voff[j]);
+            }
         });
     };
 
@@ -328,6 +409,8 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     // scores of tile 0 and their row max: the first reference point
     f32x16 s_cur[KB], s_next[KB];
     hd_scores<D, KB>(ring, g, qf, s_cur);
+    if constexpr (MASKED)
+        if (needs_mask(0)) hd_mask_scores<KB>(s_cur, key_limit - 4 * g.hh);
     float m_run = hd_row_max<KB>(s_cur, c);
 
     // One step per tile.  The loop below is STAGES copies of it, one per ring stage, so that every stage offset is a
@@ -344,15 +427,36 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
         const half_t* kt2 = kh + (size_t)t2 * TK * D;
         const half_t* vt2 = vh + (size_t)t2 * TK * D;
         const unsigned l2 = d_lds + (unsigned)(ST2 * kStage);
+        // MASKED: the offsets of this step's pieces, those of the cut tile when it is the one sent for (chosen here,
+        // outside the block; the pieces then carry their LDS address in m0 and no immediate)
+        [[maybe_unused]] unsigned ko[PPW], vo[PPW];
+        if constexpr (MASKED) {
+            const bool cut = ragged_end && t2 == last_key_tile;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                ko[j] = cut ? d_koff_end[j] : d_koff[j] + 1024u * j;
+                vo[j] = cut ? d_voff_end[j] : d_voff[j] + 1024u * j;
+            }
+        }
         auto dma_step = [&](auto jc) {
 #ifndef FA_HD_ABLATE_DMA  // (the FA_HD_ABLATE_* builds are timing experiments: wrong results)
             constexpr int j = decltype(jc)::value;
-            if constexpr (j == 0) dma_set_base(l2);
-            if constexpr (j == PPW) dma_set_base(l2 + (unsigned)kTile);
-            if constexpr (j < PPW)
-                dma_piece_at<1024 * j>(kt2, d_koff[j]);
-            else
-                dma_piece_at<1024 * (j - PPW)>(vt2, d_voff[j - PPW]);
+            if constexpr (MASKED) {
+                if constexpr (j < PPW) {
+                    dma_set_base(l2 + 1024u * j);
+                    dma_piece_at<0>(kt2, ko[j]);
+                } else {
+                    dma_set_base(l2 + (unsigned)kTile + 1024u * (j - PPW));
+                    dma_piece_at<0>(vt2, vo[j - PPW]);
+                }
+            } else {
+                if constexpr (j == 0) dma_set_base(l2);
+                if constexpr (j == PPW) dma_set_base(l2 + (unsigned)kTile);
+                if constexpr (j < PPW)
+                    dma_piece_at<1024 * j>(kt2, d_koff[j]);
+                else
+                    dma_piece_at<1024 * (j - PPW)>(vt2, d_voff[j - PPW]);
+            }
 #endif
         };
         auto dma_none = [&](auto) {};
@@ -360,6 +464,12 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
         float mx = m_run;
         if (__builtin_expect(more, 1)) {
             hd_block1<D, KB, true, 2 * PPW>(ring + ST1 * kStage, g, qf, s_next, s_cur, c, m_run, l_run, pf, dma_step);
+            if constexpr (MASKED)
+                if (__builtin_expect(needs_mask(t + 1), 0)) {
+#pragma unroll
+                    for (int b = 0; b < KB; ++b) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s_next[b]));  // MFMA result -> vector reader
+                    hd_mask_scores<KB>(s_next, key_limit - (t + 1) * TK - 4 * g.hh);
+                }
             hd_block2<D, KB, true>(ring + ST * kStage + kTile, g, pf, s_next, c, mx);
             if (__builtin_expect(!__all(mx - m_run <= kRescaleSlack), 0)) {
                 const float m_new = fmaxf(m_run, mx);
@@ -399,7 +509,7 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     acc_fence();
     const float l_tot = half_wave_sum(l_run);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-    if (wave_valid) {
+    if (MASKED ? (wave_valid && q_row0 + g.r < lq_v) : wave_valid) {
         half_t* og = p.o + srow * D;
         static_for<HD::kBlocks * 4>([&](auto ic) {
             constexpr int i = decltype(ic)::value, db = i / 4, g4 = i % 4;
@@ -411,6 +521,16 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
             *reinterpret_cast<half4*>(og + 32 * db + 8 * g4 + 4 * g.hh) = __builtin_convertvector(v, half4);
         });
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_kernel(const FwdParams p) {
+    fa_fwd_hd_body<D, false>(p);
+}
+// The same with the causal mask, any lengths and padded batches.
+template <int D>
+__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_masked_kernel(const FwdParams p) {
+    fa_fwd_hd_body<D, true>(p);
 }
 
 }  // namespace fa

@@ -48,7 +48,7 @@ int fail(int code, const char* fmt, const char* detail = "") {
 //   FA_MASKED_W64=1 / 0  masked forms of that kernel wherever they can run / nowhere (default: where measured faster)
 //   FA_BLOCK_TUNED=0     fa_forward_block_general keeps every block on the general kernel
 //   FA_SPLIT=0 / n       never split an item's keys over workgroups / over n of them (default: by the cost model)
-//   FA_HD=0              head dims 64 / 256 stay on the general kernel
+//   FA_HD=0 / 1          head dims 64 / 256 stay on the general kernel / only their unmasked whole-tile shapes leave it
 //   FA_RESERVED_CUS=k    initial value of fa_set_reserved_cus()
 //   FA_NWAVES=4, FA_RING=0   (builds with -DFA_AB_KERNELS only) the register-staged kernels kept for comparisons
 struct Switches {
@@ -59,7 +59,7 @@ struct Switches {
     int masked_w64 = -1;  // -1: the library's own choice
     bool block_tuned = true;
     int split = -1;  // -1: the cost model's choice
-    bool hd = true;
+    bool hd = true, hd_masked = true;
 };
 std::atomic<const Switches*> g_switches{nullptr};
 std::once_flag g_switches_once;
@@ -82,7 +82,7 @@ const Switches* read_switches() {
     if (geti("FA_MASKED_W64", x)) sw->masked_w64 = x != 0;
     if (geti("FA_BLOCK_TUNED", x)) sw->block_tuned = x != 0;
     if (geti("FA_SPLIT", x) && x >= 0) sw->split = x;
-    if (geti("FA_HD", x)) sw->hd = x != 0;
+    if (geti("FA_HD", x)) sw->hd = x != 0, sw->hd_masked = x != 1;
     if (geti("FA_RESERVED_CUS", x) && x >= 0) g_reserved_cus.store(x, std::memory_order_relaxed);
     return sw;
 }
@@ -368,24 +368,38 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
     return FA_OK;
 }
 
-// Head dims 64 and 256 in whole tiles without a mask: fa_fwd_hd_kernel<D> (FA_HD=0 keeps them on the general kernel).
-bool hd_kernel_takes(int flags, int D, int lq, int lk) {
-    if (flags != 0 || !switches().hd) return false;
-    if (D == 256) return lq % 64 == 0 && lk % 64 == 0;
-    if (D == 64) return lq % 64 == 0 && lk % fa::HdCfg<64>::kTk == 0;
-    return false;
+// Head dims 64 and 256 on fa_fwd_hd_kernel<D> (FA_HD=0 keeps them on the general kernel): whole tiles without a mask
+// on its plain form, everything else that is not blockwise (the causal mask, any lengths, padded batches) on its
+// masked form.
+enum HdRoute { kHdNone, kHdPlain, kHdMasked };
+HdRoute hd_route(int flags, int D, int lq, int lk) {
+    if ((D != 64 && D != 256) || !switches().hd || (flags & ~FA_FLAG_CAUSAL)) return kHdNone;
+    const int tk = D == 64 ? fa::HdCfg<64>::kTk : fa::HdCfg<256>::kTk;
+    if (flags == 0 && lq % 64 == 0 && lk % 64 == 0 && lk % tk == 0) return kHdPlain;
+    return switches().hd_masked ? kHdMasked : kHdNone;
+}
+const char* hd_name(HdRoute r, int D) {
+    if (r == kHdPlain) return D == 64 ? "fa::fa_fwd_hd_kernel<64>" : "fa::fa_fwd_hd_kernel<256>";
+    return D == 64 ? "fa::fa_fwd_hd_masked_kernel<64>" : "fa::fa_fwd_hd_masked_kernel<256>";
 }
 template <int D>
-int launch_hd(const fa::FwdParams& base, hipStream_t stream) {
+int launch_hd(const fa::FwdParams& base, bool masked, hipStream_t stream) {
     fa::FwdParams p = base;
     constexpr int kBlockRows = fa::HdCfg<D>::kWaves * fa::kRowsPerWave;
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
     p.q_blocks = (p.lq + kBlockRows - 1) / kBlockRows;
     const long items = (long)p.bh * p.q_blocks;
     if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
-    hipLaunchKernelGGL(fa::fa_fwd_hd_kernel<D>, dim3((unsigned)items), dim3(fa::HdCfg<D>::kWaves * 64), 0, stream, p);
+    const dim3 grid((unsigned)items), block(fa::HdCfg<D>::kWaves * 64);
+    if (masked)
+        hipLaunchKernelGGL(fa::fa_fwd_hd_masked_kernel<D>, grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL(fa::fa_fwd_hd_kernel<D>, grid, block, 0, stream, p);
     FA_HIP(hipGetLastError());
     return FA_OK;
+}
+int launch_hd_any(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) {
+    return D == 64 ? launch_hd<64>(p, r == kHdMasked, stream) : launch_hd<256>(p, r == kHdMasked, stream);
 }
 
 // The masked forms of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
@@ -567,7 +581,7 @@ const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
         p.lq = lq, p.lk = lk, p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
         return masked_w64_name(p);
     }
-    if (hd_kernel_takes(flags, D, lq, lk)) return D == 64 ? "fa::fa_fwd_hd_kernel<64>" : "fa::fa_fwd_hd_kernel<256>";
+    if (const HdRoute r = hd_route(flags, D, lq, lk)) return hd_name(r, D);
     return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
 }
 
@@ -635,9 +649,8 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     }
     if (masked_on_w64(flags, D, Lq, Lk))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_masked(p, stream); });
-    if (hd_kernel_takes(flags, D, Lq, Lk))
-        return timed_launch(stream, elapsed_ms,
-                            [&]() -> int { return D == 64 ? launch_hd<64>(p, stream) : launch_hd<256>(p, stream); });
+    if (const HdRoute r = hd_route(flags, D, Lq, Lk))
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_any(p, D, r, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 
@@ -666,6 +679,8 @@ int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV
     p.q_len = d_q_len;
     p.k_len = d_k_len;
     p.heads_per_batch = H;
+    if ((D == 64 || D == 256) && switches().hd && switches().hd_masked)
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_any(p, D, kHdMasked, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 

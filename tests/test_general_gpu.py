@@ -125,7 +125,7 @@ def test_masked_kernel_choice(fa, fa_env):
         assert name(Lq, Lk, 128, 0) == masked_tuned(Lq, Lk, False)
     for Lq, Lk in ((63, 1000), (511, 191), (1, 5000), (257, 512), (100, 4000), (321, 321)):
         assert name(Lq, Lk, 128, 0) == general
-    assert name(512, 512, 64, 1) == b"fa::fa_fwd_general_kernel<64>" and name(511, 511, 256, 0).endswith(b"<256>")
+    assert name(512, 512, 64, 1) == b"fa::fa_fwd_hd_masked_kernel<64>" and name(511, 511, 256, 0) == b"fa::fa_fwd_hd_masked_kernel<256>"
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
     fa_env(FA_MASKED_W64="1")
     for L in (320, 200, 577):
@@ -631,3 +631,54 @@ def test_other_head_dims_rescale_and_repeat(fa, oracle, dev, D, fa_env):
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
     gate(oracle, oracle.attention_cpu(Q, K, V), o1.cpu().numpy(), f"D={D} spiked")
+
+
+@pytest.mark.parametrize("D", [64, 256])
+@pytest.mark.parametrize("Lq,Lk,causal", [
+    (1, 1, False), (1, 1, True), (5, 5, True), (33, 33, True), (64, 64, True), (65, 65, True), (128, 128, True),
+    (200, 200, True), (513, 513, True), (1000, 1000, True), (1, 500, False), (100, 64, False), (130, 1000, False),
+    (512, 77, False), (257, 3, False), (300, 31, False), (64, 129, False), (129, 2048, False),
+])
+def test_other_head_dims_masked_form(fa, oracle, dev, D, Lq, Lk, causal, fa_env):
+    """D = 64 / 256 with the causal mask, lengths that are not whole tiles (down to one row, fewer keys than a tile) and
+    Lq != Lk run on fa_fwd_hd_masked_kernel<D>: whole tensors against the oracle, NaN behind the inputs and a sentinel
+    behind the output (run_general), and within rounding the general kernel's result."""
+    fa_env(FA_HD=None)
+    flags = 1 if causal else 0
+    assert fa.lib().fa_kernel_name_general(Lq, Lk, D, flags) == f"fa::fa_fwd_hd_masked_kernel<{D}>".encode()
+    rng = np.random.default_rng(7 * D + Lq + 3 * Lk)
+    Q = rng.standard_normal((2, 3, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((2, 3, Lk, D), dtype=np.float32).astype(np.float16)
+    V = (rng.standard_normal((2, 3, Lk, D), dtype=np.float32) * 0.5).astype(np.float16)
+    O = run_general(fa, dev, Q, K, V, causal=causal)
+    if Lq == Lk:
+        ref = oracle.attention_cpu(Q, K, V, causal=causal)
+    else:
+        st = oracle.BlockState(2, 3, Lq, D)
+        oracle.block_update(st, Q, K, V)
+        ref = oracle.block_finalize(st)
+    gate(oracle, ref, O, f"D={D} Lq={Lq} Lk={Lk} causal={causal}")
+    fa_env(FA_HD="1")  # (1: only the unmasked whole-tile shapes leave the general kernel)
+    assert fa.lib().fa_kernel_name_general(Lq, Lk, D, flags) == f"fa::fa_fwd_general_kernel<{D}>".encode()
+    O2 = run_general(fa, dev, Q, K, V, causal=causal)
+    assert np.abs(O.astype(np.float32) - O2.astype(np.float32)).max() <= 1e-3
+
+
+@pytest.mark.parametrize("D", [64, 256])
+def test_other_head_dims_causal_many_blocks(fa, oracle, dev, D, fa_env):
+    """Causal, several heads and query blocks (the long blocks are handed out first), a ragged length on top:
+    sampled rows against the oracle over the whole sequence."""
+    import torch
+
+    fa_env(FA_HD=None)
+    L = 2100
+    Q, K, V = normal_fp16(500 + D, (2, 5, L, D))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = fa.attention_general(q, k, v, causal=True)
+    torch.cuda.synchronize()
+    rows = np.unique(np.concatenate([np.arange(0, L, 97), [L - 1, 127, 128, 129, 2047, 2048]])).astype(np.int32)
+    ref = oracle.attention_cpu_rows(Q, K, V, rows, causal=True)
+    m = oracle.error_metrics(ref, o.cpu().numpy()[:, :, rows])
+    # (the first rows of a causal sequence average few values: |O| reaches 2 to 4 there, where fp16 neighbours lie
+    # 2e-3 apart, so the absolute bound scales with |O| above 1)
+    assert m["max_abs"] <= MAX_ABS_TOL * max(1.0, float(np.abs(ref).max())) and m["global_rel"] <= REL_L2_TOL, m

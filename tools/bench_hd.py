@@ -15,6 +15,7 @@ ap.add_argument("--dims", type=int, nargs="+", default=[64, 256])
 ap.add_argument("--shapes", type=int, nargs="+", default=[2048, 8192])
 ap.add_argument("--causal", action="store_true")
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--lminus", type=int, default=0, help="shorten every L by this much (ragged lengths)")
 args = ap.parse_args()
 fa = ge.load_package()
 libs = [("product", fa.lib())] + [(os.path.basename(p), fa.bind(os.path.join(ROOT, p))) for p in args.libs]
@@ -23,6 +24,7 @@ H = 16
 for D in args.dims:
     for L in args.shapes:
         B = max(1, 16384 // L)
+        L -= args.lminus
         q, k, v = [torch.empty((B, H, L, D), dtype=torch.float16, device=dev) for _ in range(3)]
         for t, seed in zip((q, k, v), (1234, 2345, 3456)):
             fa.init_half(t, seed)
