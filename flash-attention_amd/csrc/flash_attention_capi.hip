@@ -284,8 +284,12 @@ int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Worksp
                 if (!ws) return FA_ERR_RUNTIME;
                 return launch_split(p, S, ws, stream);
             }
+            // (a stream under capture would turn the allocation into graph nodes; such callers get the unsplit
+            // launch here and the split one, workspace included, from fa_forward_noalloc)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
             void* ws = nullptr;
-            if (hipMallocAsync(&ws, bytes, stream) == hipSuccess && ws) {
+            if (!capturing && hipMallocAsync(&ws, bytes, stream) == hipSuccess && ws) {
                 const int rc = launch_split(p, S, ws, stream);
                 (void)hipFreeAsync(ws, stream);
                 return rc;

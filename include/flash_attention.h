@@ -80,7 +80,8 @@ enum {
  * second, small kernel.  The reference never meets this: its grid is (L/64, B, H) workgroups of 64 rows
  * (wrapper.cu:74-76).  The workspace (520 bytes per query row and range) is taken from the stream's memory pool
  * (hipMallocAsync / hipFreeAsync: stream-ordered, no device synchronisation) and returned to it by the same call;
- * other launches allocate nothing. */
+ * other launches allocate nothing.  On a stream under capture nothing is allocated: such a shape is launched
+ * undivided there (fa_forward_noalloc launches the divided form in a capture as well). */
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
                int D, int tile, void* stream, float* elapsed_ms);
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,

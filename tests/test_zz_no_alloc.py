@@ -97,3 +97,27 @@ def test_noalloc_rejects_what_does_not_fit_and_bad_arguments(fa, dev, fa_env):
     assert L_.fa_forward_noalloc(z, z, z, z, 1, 1, 100, 128, 64, None) == 2   # L % 64
     assert L_.fa_forward_noalloc(z, z, z, z, 1, 1, 64, 64, 64, None) == 3     # D
     assert L_.fa_forward_noalloc(None, z, z, z, 1, 1, 64, 128, 64, None) == 5  # NULL pointer
+
+
+def test_split_shapes_under_stream_capture(fa, dev, fa_env):
+    """A shape that divides its keys, captured in a graph: fa_forward launches it unsplit there (no allocation inside a
+    capture), fa_forward_noalloc launches the split form on the static scratch buffer; both replay to the eager bits."""
+    import torch
+
+    fa_env(FA_SPLIT=None)
+    q, k, v = _inputs(dev, 11, (1, 2, 8192, 128))
+    assert fa.lib().fa_split_ways(2, 8192, 8192) > 1
+    eager = torch.empty_like(q)
+    assert _call(fa, "fa_forward", q, k, v, eager) == 0
+    warm = torch.empty_like(q)
+    assert _call(fa, "fa_forward_noalloc", q, k, v, warm) == 0  # first call on the device: outside any capture
+    torch.cuda.synchronize()
+    o1, o2 = torch.zeros_like(q), torch.zeros_like(q)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert _call(fa, "fa_forward", q, k, v, o1) == 0
+        assert _call(fa, "fa_forward_noalloc", q, k, v, o2) == 0
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o2, eager)                       # the same kernels as the eager split launch
+    assert (o1.float() - eager.float()).abs().max().item() <= 1e-3  # unsplit: other summation order
