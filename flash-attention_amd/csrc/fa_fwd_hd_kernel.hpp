@@ -1,7 +1,7 @@
-// Forward kernel for head dims 64 and 256, whole tiles, no mask (fa_forward_general with Lq % 64 == 0,
-// Lk % 64 == 0).  The reference fixes D = 128 (cuda_utils.cuh:11) and lists other head dims as future work
-// (README.md:47); fa_fwd_general_kernel<D> serves them for every shape, this kernel serves the whole-tile shapes
-// faster.
+// Forward kernel for head dims 64 and 256 (every shape that is not blockwise) and for the D = 128 shapes that the
+// one-wave-per-SIMD kernel does not take.  The reference fixes D = 128 (cuda_utils.cuh:11), L % 64 == 0
+// (wrapper.cu:59-61) and has no mask; its README lists all three as future work (README.md:44-47).
+// fa_fwd_general_kernel<D> serves every such shape too (and the blockwise entry point); this kernel is faster.
 //
 // What it keeps from the D = 128 kernels: transposed scores S^T = K.Q^T with v_mfma_f32_32x32x16_f16, P straight
 // from the score registers into O^T += V^T.P^T, K/V tiles travelling global -> LDS by DMA (global_load_lds_dwordx4,
@@ -43,6 +43,17 @@ struct HdCfg<256> {
 #endif
     static constexpr int kAhead = FA_HD256_AHEAD;  // operand fragments read this many MFMAs ahead of their use
 };
+// D = 128: only the masked form is used, for the shapes the one-wave-per-SIMD kernel and its masked forms do not take
+// (short or mostly empty last blocks, padded batches).  32-key tiles keep a workgroup at 48 KiB of LDS and 150 + 64
+// registers, so that two share a CU (with 64-key tiles and one workgroup per CU it lost to fa_fwd_general_kernel<128>).
+template <>
+struct HdCfg<128> {
+    static constexpr int kWaves = 4;
+    static constexpr int kTk = 32;
+    static constexpr int kStages = 3;
+    static constexpr int kOcc = 2;
+    static constexpr int kAhead = 4;
+};
 #ifndef FA_HD64_WAVES
 #define FA_HD64_WAVES 4
 #define FA_HD64_TK 64
@@ -76,6 +87,12 @@ __device__ __forceinline__ void mfma_vv(f32x16& d, const half8& a, const half8& 
 __device__ __forceinline__ void acc_reserve32() {
     asm volatile("" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15",
                  "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+}
+__device__ __forceinline__ void acc_reserve64() {
+    asm volatile("" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15",
+                 "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31",
+                 "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47",
+                 "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
 }
 // a[LO : LO+15] = 0 through the matrix pipe; a[BASE : BASE+N-1] *= alpha through the vector ALU (rare: the rescale).
 template <int LO>
@@ -402,6 +419,8 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     __syncthreads();
     if constexpr (D == 64)
         acc_reserve32();
+    else if constexpr (D == 128)
+        acc_reserve64();
     else
         acc_reserve();
     static_for<HD::kBlocks>([&](auto ic) { acc_zero16<16 * decltype(ic)::value>(); });

@@ -48,7 +48,7 @@ int fail(int code, const char* fmt, const char* detail = "") {
 //   FA_MASKED_W64=1 / 0  masked forms of that kernel wherever they can run / nowhere (default: where measured faster)
 //   FA_BLOCK_TUNED=0     fa_forward_block_general keeps every block on the general kernel
 //   FA_SPLIT=0 / n       never split an item's keys over workgroups / over n of them (default: by the cost model)
-//   FA_HD=0 / 1          head dims 64 / 256 stay on the general kernel / only their unmasked whole-tile shapes leave it
+//   FA_HD=0 / 1          everything the D = 128 tuned kernels leave stays on the general kernel / only unmasked whole-tile D = 64, 256 leave it
 //   FA_RESERVED_CUS=k    initial value of fa_set_reserved_cus()
 //   FA_NWAVES=4, FA_RING=0   (builds with -DFA_AB_KERNELS only) the register-staged kernels kept for comparisons
 struct Switches {
@@ -374,15 +374,18 @@ int launch_general(const fa::FwdParams& base, int D, hipStream_t stream) {
 
 // Head dims 64 and 256 on fa_fwd_hd_kernel<D> (FA_HD=0 keeps them on the general kernel): whole tiles without a mask
 // on its plain form, everything else that is not blockwise (the causal mask, any lengths, padded batches) on its
-// masked form.
+// masked form; the masked form also takes the D = 128 shapes that used to run on the general kernel.
 enum HdRoute { kHdNone, kHdPlain, kHdMasked };
 HdRoute hd_route(int flags, int D, int lq, int lk) {
+    // (D = 128: what reaches here is masked, ragged or short: the masked form)
+    if (D == 128) return switches().hd && switches().hd_masked && !(flags & ~FA_FLAG_CAUSAL) ? kHdMasked : kHdNone;
     if ((D != 64 && D != 256) || !switches().hd || (flags & ~FA_FLAG_CAUSAL)) return kHdNone;
     const int tk = D == 64 ? fa::HdCfg<64>::kTk : fa::HdCfg<256>::kTk;
     if (flags == 0 && lq % 64 == 0 && lk % 64 == 0 && lk % tk == 0) return kHdPlain;
     return switches().hd_masked ? kHdMasked : kHdNone;
 }
 const char* hd_name(HdRoute r, int D) {
+    if (D == 128) return "fa::fa_fwd_hd_masked_kernel<128>";
     if (r == kHdPlain) return D == 64 ? "fa::fa_fwd_hd_kernel<64>" : "fa::fa_fwd_hd_kernel<256>";
     return D == 64 ? "fa::fa_fwd_hd_masked_kernel<64>" : "fa::fa_fwd_hd_masked_kernel<256>";
 }
@@ -403,25 +406,38 @@ int launch_hd(const fa::FwdParams& base, bool masked, hipStream_t stream) {
     return FA_OK;
 }
 int launch_hd_any(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) {
+    if (D == 128) return launch_hd<128>(p, true, stream);
     return D == 64 ? launch_hd<64>(p, r == kHdMasked, stream) : launch_hd<256>(p, r == kHdMasked, stream);
 }
 
 // The masked forms of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
-// that are not whole tiles; they need Lq >= 64 (a wave's rows) and three tiles of keys.  Against the general
-// kernel (128-row workgroups) they lose where the last 256-row query block is at most half full and the
+// that are not whole tiles; they need Lq >= 64 (a wave's rows) and three tiles of keys.  Against the kernels
+// with 128-row workgroups they lose where the last 256-row query block is at most half full and the
 // sequence short, because its idle waves then weigh more than the faster loop gains.  Measured
-// (tools/bench_general.py --ragged-sweep --fine, B*L = 16384, H = 16): without the mask they win from
-// Lq = 512 on and below that with more than 128 rows in the last block; with the mask from Lq = 1088 on, from
-// 385 on with more than 128 rows in the last block, and at 192 and 256.  FA_MASKED_W64=1 takes them wherever
-// they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests; see Switches).
-bool masked_on_w64(int flags, int D, int lq, int lk) {
+// (tools/bench_general.py --ragged-sweep --fine, B*L = 16384, H = 16).  Against fa_fwd_general_kernel<128>
+// (`blockwise`: the alternative of the blockwise entry point): without the mask they win from Lq = 512 on and
+// below that with more than 128 rows in the last block; with the mask from Lq = 1088 on, from 385 on with
+// more than 128 rows in the last block, and at 192 and 256.  Against fa_fwd_hd_masked_kernel<128> (the
+// alternative everywhere else), which is 10 - 20 % faster than the general kernel: without the mask from
+// Lq = 832 on, below that with more than 128 rows in the last block; with the mask in whole tiles when the last
+// block holds more than 128 rows or from Lq = 1344 on, with ragged lengths (their form of the kernel is some
+// 15 % slower on short sequences) from Lq = 897 on when the last block holds more than 128 rows, else from 1793.
+// FA_MASKED_W64=1 takes them wherever they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests; see
+// Switches).
+bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false) {
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (D != fa::kHeadDim || lq < 64 || lk < 3 * fa::kKvTile || (causal && lq != lk)) return false;
     if (!causal && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return false;  // the unmasked kernels' shapes
     if (switches().masked_w64 >= 0) return switches().masked_w64 != 0;
     const int last_block_rows = (lq - 1) % 256 + 1;
-    if (!causal) return lq >= 512 || last_block_rows > 128;
-    return lq >= 1088 || (lq >= 385 && last_block_rows > 128) || lq == 192 || lq == 256;
+    if (blockwise || !switches().hd || !switches().hd_masked) {
+        if (!causal) return lq >= 512 || last_block_rows > 128;
+        return lq >= 1088 || (lq >= 385 && last_block_rows > 128) || lq == 192 || lq == 256;
+    }
+    if (!causal) return lq >= 832 || last_block_rows > 128;
+    const bool ragged = lq % fa::kKvTile != 0;
+    if (last_block_rows > 128) return !ragged || lq >= 897;
+    return lq >= (ragged ? 1793 : 1344);
 }
 // (which of its instantiations: by the mask flag and by whether both lengths are whole tiles)
 const char* masked_w64_name(const fa::FwdParams& p) {
@@ -465,9 +481,9 @@ BlockRoute block_route(int lq, int lk, int D, int flags, int q_pos0, int k_pos0)
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (!causal || (long)k_pos0 + lk - 1 <= (long)q_pos0) {
         if (whole) return kRouteTuned;
-        return masked_on_w64(0, D, lq, lk) ? kRouteUnmaskedRaggedW64 : kRouteGeneral;
+        return masked_on_w64(0, D, lq, lk, true) ? kRouteUnmaskedRaggedW64 : kRouteGeneral;
     }
-    if (q_pos0 == k_pos0 && masked_on_w64(flags, D, lq, lk)) return kRouteMaskedW64;
+    if (q_pos0 == k_pos0 && masked_on_w64(flags, D, lq, lk, true)) return kRouteMaskedW64;
     return kRouteGeneral;
 }
 
@@ -683,7 +699,7 @@ int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV
     p.q_len = d_q_len;
     p.k_len = d_k_len;
     p.heads_per_batch = H;
-    if ((D == 64 || D == 256) && switches().hd && switches().hd_masked)
+    if (switches().hd && switches().hd_masked)
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_any(p, D, kHdMasked, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }

@@ -112,19 +112,26 @@ def masked_tuned(Lq, Lk, causal):
 
 def test_masked_kernel_choice(fa, fa_env):
     """D = 128 with the causal mask or ragged lengths: the masked forms of the one-wave-per-SIMD kernel where they
-    were measured faster than the general kernel (long sequences, or a last 256-row block more than half full);
-    FA_MASKED_W64=1 extends them to every shape they can run (Lq >= 64, three tiles of keys)."""
+    were measured faster than 128-row workgroups (long sequences, or a last 256-row block more than half full), else
+    the masked form of the pipelined 128-row kernel (`general` below; FA_HD=0 / 1 would put fa_fwd_general_kernel<128>
+    in its place); FA_MASKED_W64=1 extends the former to every shape they can run (Lq >= 64, three tiles of keys)."""
     name = fa.lib().fa_kernel_name_general
-    general = b"fa::fa_fwd_general_kernel<128>"
+    general = b"fa::fa_fwd_hd_masked_kernel<128>"
+    fa_env(FA_HD=None)
     fa_env(FA_MASKED_W64=None)
-    for L in (192, 256, 448, 500, 512, 700, 1088, 16383, 16384):
+    for L in (192, 256, 448, 512, 960, 1000, 1344, 1793, 16383, 16384):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
-    for L in (64, 128, 193, 320, 384, 576, 640, 1025):
+    for L in (64, 128, 193, 320, 384, 500, 576, 640, 700, 1025, 1088, 1537):
         assert name(L, L, 128, 1) == general
-    for Lq, Lk in ((511, 511), (2047, 2047), (193, 1000), (600, 320), (513, 513)):
+    for Lq, Lk in ((511, 511), (2047, 2047), (193, 1000), (900, 320), (1025, 1025)):
         assert name(Lq, Lk, 128, 0) == masked_tuned(Lq, Lk, False)
-    for Lq, Lk in ((63, 1000), (511, 191), (1, 5000), (257, 512), (100, 4000), (321, 321)):
+    for Lq, Lk in ((63, 1000), (511, 191), (1, 5000), (257, 512), (100, 4000), (321, 321), (600, 320), (513, 513)):
         assert name(Lq, Lk, 128, 0) == general
+    fa_env(FA_HD="1")  # (against the general kernel the tuned forms win earlier)
+    for L in (500, 700, 1088):
+        assert name(L, L, 128, 1) == masked_tuned(L, L, True)
+    assert name(600, 320, 128, 0) == masked_tuned(600, 320, False)
+    fa_env(FA_HD=None)
     assert name(512, 512, 64, 1) == b"fa::fa_fwd_hd_masked_kernel<64>" and name(511, 511, 256, 0) == b"fa::fa_fwd_hd_masked_kernel<256>"
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
     fa_env(FA_MASKED_W64="1")
@@ -134,6 +141,8 @@ def test_masked_kernel_choice(fa, fa_env):
     assert name(128, 128, 128, 1) == general and name(63, 500, 128, 0) == general and name(100, 191, 128, 0) == general
     fa_env(FA_MASKED_W64="0")
     assert name(512, 512, 128, 1) == general and name(511, 511, 128, 0) == general
+    fa_env(FA_HD="1")
+    assert name(512, 512, 128, 1) == b"fa::fa_fwd_general_kernel<128>" == name(63, 1000, 128, 0)
 
 
 @pytest.mark.parametrize("B,H,L", [(2, 2, 192), (1, 3, 256), (2, 3, 320), (1, 5, 448), (2, 4, 512), (1, 3, 576),
@@ -163,7 +172,7 @@ def test_causal_tuned_kernel_item_order(fa, oracle, dev, B, H, L, fa_env):
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
     o = torch.full_like(q, float("nan"))
     fa.attention_general(q, k, v, causal=True, out=o)
-    fa_env(FA_MASKED_W64="0")
+    fa_env(FA_MASKED_W64="0", FA_HD="1")
     assert fa.lib().fa_kernel_name_general(L, L, 128, 1) == b"fa::fa_fwd_general_kernel<128>"
     o_ref = fa.attention_general(q, k, v, causal=True)
     torch.cuda.synchronize()
@@ -207,7 +216,7 @@ def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, fa_env
     against the oracle."""
     import torch
 
-    fa_env(FA_MASKED_W64=None)
+    fa_env(FA_MASKED_W64="1")
     assert fa.lib().fa_kernel_name_general(L, L, 128, int(causal)) == masked_tuned(L, L, causal)
     Q, K, V = normal_fp16(500 + L, (B, H, L, 128))
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
@@ -633,17 +642,17 @@ def test_other_head_dims_rescale_and_repeat(fa, oracle, dev, D, fa_env):
     gate(oracle, oracle.attention_cpu(Q, K, V), o1.cpu().numpy(), f"D={D} spiked")
 
 
-@pytest.mark.parametrize("D", [64, 256])
+@pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("Lq,Lk,causal", [
     (1, 1, False), (1, 1, True), (5, 5, True), (33, 33, True), (64, 64, True), (65, 65, True), (128, 128, True),
     (200, 200, True), (513, 513, True), (1000, 1000, True), (1, 500, False), (100, 64, False), (130, 1000, False),
     (512, 77, False), (257, 3, False), (300, 31, False), (64, 129, False), (129, 2048, False),
 ])
 def test_other_head_dims_masked_form(fa, oracle, dev, D, Lq, Lk, causal, fa_env):
-    """D = 64 / 256 with the causal mask, lengths that are not whole tiles (down to one row, fewer keys than a tile) and
+    """D = 64 / 128 / 256 with the causal mask, lengths that are not whole tiles (down to one row, fewer keys than a tile) and
     Lq != Lk run on fa_fwd_hd_masked_kernel<D>: whole tensors against the oracle, NaN behind the inputs and a sentinel
     behind the output (run_general), and within rounding the general kernel's result."""
-    fa_env(FA_HD=None)
+    fa_env(FA_HD=None, FA_MASKED_W64="0")  # (D = 128: the one-wave-per-SIMD kernel's masked forms would take some)
     flags = 1 if causal else 0
     assert fa.lib().fa_kernel_name_general(Lq, Lk, D, flags) == f"fa::fa_fwd_hd_masked_kernel<{D}>".encode()
     rng = np.random.default_rng(7 * D + Lq + 3 * Lk)
@@ -664,13 +673,13 @@ def test_other_head_dims_masked_form(fa, oracle, dev, D, Lq, Lk, causal, fa_env)
     assert np.abs(O.astype(np.float32) - O2.astype(np.float32)).max() <= 1e-3
 
 
-@pytest.mark.parametrize("D", [64, 256])
+@pytest.mark.parametrize("D", [64, 128, 256])
 def test_other_head_dims_causal_many_blocks(fa, oracle, dev, D, fa_env):
     """Causal, several heads and query blocks (the long blocks are handed out first), a ragged length on top:
     sampled rows against the oracle over the whole sequence."""
     import torch
 
-    fa_env(FA_HD=None)
+    fa_env(FA_HD=None, FA_MASKED_W64="0")
     L = 2100
     Q, K, V = normal_fp16(500 + D, (2, 5, L, D))
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]

@@ -5,7 +5,9 @@
 
 Pattern data of the reference's throughput driver, 1 s of preheat, back-to-back launches between two
 events.  FLOPs: 4*B*H*Lq*Lk*D without mask, half of that (the visible triangle, diagonal included:
-2*B*H*L*(L+1)*D) with the causal mask.  --causal-sweep / --ragged-sweep: the masked tuned kernel and the general kernel side by side over L."""
+2*B*H*L*(L+1)*D) with the causal mask.  --causal-sweep / --ragged-sweep: the masked tuned kernel (FA_MASKED_W64=1) and the 128-row kernel
+that takes its place (FA_MASKED_W64=0: labelled "general kernel"; fa_fwd_hd_masked_kernel<128>, or
+fa_fwd_general_kernel<128> with FA_HD=1 in the environment) side by side over L; --only-sweep skips the table before it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -46,7 +48,7 @@ def run(label, B, L, causal, general=True, reps=20, D=128, tuned_causal=True):
     flops = 2.0 * B * H * L * (L + 1) * D if causal else 4.0 * B * H * L * L * D
     print(f"{label:44s} B={B:2d} L={L:5d} D={D:3d}  {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s")
 
-for B, L in ((32, 512), (8, 2048), (1, 16384)):
+for B, L in () if "--only-sweep" in sys.argv else ((32, 512), (8, 2048), (1, 16384)):
     run("tuned kernel, no mask", B, L, False, general=False)
     run("masked tuned kernel, no mask, L-1 (ragged)", B, L - 1, False)
     run("general kernel, no mask, L-1 (ragged)", B, L - 1, False, tuned_causal=False)
@@ -55,7 +57,7 @@ for B, L in ((32, 512), (8, 2048), (1, 16384)):
     run("masked tuned kernel, causal, L-1", B, L - 1, True)
     run("general kernel, causal, L-1", B, L - 1, True, tuned_causal=False)
 if "--ragged-sweep" in sys.argv:
-    Ls = [L for L0 in range(192, 1345, 64) for L in (L0, L0 + 1)] if "--fine" in sys.argv else (193, 257, 321, 385, 449, 511, 577, 767, 1023)
+    Ls = [L for L0 in range(192, 2305, 64) for L in (L0, L0 + 1)] if "--fine" in sys.argv else (193, 257, 321, 385, 449, 511, 577, 767, 1023)
     for L in Ls:
         B = max(1, 16384 // L)
         for causal in (False, True):
