@@ -24,6 +24,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 namespace fa {
 
@@ -36,6 +38,17 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP's uint4 is a struct
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ...
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 constexpr int kHeadDim = 128;     // D
 constexpr int kKvTile = 64;       // keys per streamed tile (the ABI's `tile`)
@@ -365,27 +378,45 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
+// How the row-wise helpers below reach the 64 elements of a sub-block's O^T (element 16 db + e): as a value
+// array here; the one-wave-per-SIMD kernel passes an accessor over the registers its inline asm owns, so that
+// no 64-register copy of the accumulator exists while the whole tile loop's state is live.
+struct ArrayAcc {
+    f32x16 (&o)[4];
+    template <int I>
+    __device__ __forceinline__ float get() const { return o[I >> 4][I & 15]; }
+    template <int I>
+    __device__ __forceinline__ void put(float x) const { o[I >> 4][I & 15] = x; }
+};
+__device__ __forceinline__ void store_staged_rows(half_t* o_rows, const char* img, int lane, int first_row);
 // O = acc / l as fp16, written through the staging image so that global stores are whole rows.
 // All eight row-wise reads are issued before the first store (the accumulators are dead by then, so
 // registers are plentiful); addresses are one base plus immediates: (4i+row0)&15 = 4(i&3) + row0, so
 // the swizzled chunk of read i is (ch ^ row0) ^ 4(i&3).
 // Rows below first_row (of the 32) are not stored.
-__device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
-                                                  float l_run, int first_row = 0) {
+template <typename ACC>
+__device__ __forceinline__ void store_output_rows_acc(half_t* o_rows, char* img, int lane, const ACC& acc, float l_run,
+                                                      int first_row = 0) {
     const float l_tot = half_wave_sum(l_run);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;  // a row that has seen no key: O = 0, not 0/0
     lane = opaque(lane);
     const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 t;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * g4 + e] * inv;
-            // columns 32db + 8g4 + 4hh .. +3  =  chunk 4db+g4, second half when hh
-            *reinterpret_cast<half4*>(img + stage_img_off(r, 4 * db + g4) + 8 * hh) = __builtin_convertvector(t, half4);
-        }
+    static_for<16>([&](auto ic) {
+        constexpr int cidx = decltype(ic)::value;  // 4 db + g4
+        const f32x4 t = {acc.template get<4 * cidx>() * inv, acc.template get<4 * cidx + 1>() * inv,
+                         acc.template get<4 * cidx + 2>() * inv, acc.template get<4 * cidx + 3>() * inv};
+        // columns 32db + 8g4 + 4hh .. +3  =  chunk 4db+g4, second half when hh
+        *reinterpret_cast<half4*>(img + stage_img_off(r, cidx) + 8 * hh) = __builtin_convertvector(t, half4);
+    });
+    store_staged_rows(o_rows, img, lane, first_row);
+}
+__device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
+                                                  float l_run, int first_row = 0) {
+    store_output_rows_acc(o_rows, img, lane, ArrayAcc{oacc}, l_run, first_row);
+}
+// The second half of the above: 32 fp16 rows that sit in the staging image go out as whole rows.
+__device__ __forceinline__ void store_staged_rows(half_t* o_rows, const char* img, int lane, int first_row) {
+    lane = opaque(lane);
     const int row0 = lane >> 4, ch = lane & 15;
     const char* rd = img + row0 * kRowBytes;
     int sw[4];
@@ -414,8 +445,9 @@ __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int
 // 32 rows x 32 bytes per instruction).  An fp32 row is 512 bytes, twice the image's row, so the accumulator
 // goes in two column halves of 64; in each the chunk index 8 (db & 1) + 2 g4 + hh takes the place of the
 // fp16 output's 4 db + g4.  `row0` is the first of the 32 rows; rows below first_row are not stored.
+template <typename ACC>
 __device__ __forceinline__ void store_state_rows(const FwdParams& p, size_t row0, char* img, int lane,
-                                                 f32x16 (&oacc)[4], float m_run, float m_true, float l_run,
+                                                 const ACC& acc, float m_run, float m_true, float l_run,
                                                  int first_row = 0) {
     // hand the state over relative to the true running max, whatever reference was in use
     const float beta = __builtin_amdgcn_exp2f(m_run - m_true);
@@ -432,17 +464,15 @@ __device__ __forceinline__ void store_state_rows(const FwdParams& p, size_t row0
 #pragma unroll
     for (int j = 0; j < 4; ++j) sw[j] = ((ch ^ rrow) ^ (4 * j)) << 4;
     float* wr = p.o_acc + (row0 + rrow) * kHeadDim + ch * 4;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int dbl = 0; dbl < 2; ++dbl)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 t;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = oacc[2 * half + dbl][4 * g4 + e] * beta;
-                *reinterpret_cast<f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh)) = t;
-            }
+    static_for<2>([&](auto hc) {
+        constexpr int half = decltype(hc)::value;
+        static_for<8>([&](auto ic) {
+            constexpr int dbl = decltype(ic)::value >> 2, g4 = decltype(ic)::value & 3;
+            constexpr int i0 = 16 * (2 * half + dbl) + 4 * g4;
+            const f32x4 t = {acc.template get<i0>() * beta, acc.template get<i0 + 1>() * beta,
+                             acc.template get<i0 + 2>() * beta, acc.template get<i0 + 3>() * beta};
+            *reinterpret_cast<f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh)) = t;
+        });
         // (four rows-of-four at a time: this runs with the whole tile loop's state live)
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
@@ -455,12 +485,13 @@ __device__ __forceinline__ void store_state_rows(const FwdParams& p, size_t row0
                 if (first_row <= 0 || 4 * (4 * grp + j) + rrow >= first_row)
                     *reinterpret_cast<u32x4*>(wr + (4 * grp + j) * 4 * kHeadDim + half * 64) = v[j];
         }
-    }
+    });
 }
 // The way back: (o_acc, row_max, row_sum) of 32 rows into a sub-block's registers (what init_state does lane by
 // lane), row pieces of 256 bytes -> image -> fragments.
+template <typename ACC>
 __device__ __forceinline__ void load_state_rows(const FwdParams& p, size_t row0, char* img, int lane,
-                                                f32x16 (&oacc)[4], float& m_run, float& m_true, float& l_run) {
+                                                const ACC& acc, float& m_run, float& m_true, float& l_run) {
     lane = opaque(lane);
     const int r = lane & 31, hh = lane >> 5;
     const float mx = p.row_max[row0 + r], sm = p.row_sum[row0 + r];
@@ -470,8 +501,8 @@ __device__ __forceinline__ void load_state_rows(const FwdParams& p, size_t row0,
 #pragma unroll
     for (int j = 0; j < 4; ++j) sw[j] = ((ch ^ rrow) ^ (4 * j)) << 4;
     const float* rd = p.o_acc + (row0 + rrow) * kHeadDim + ch * 4;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    static_for<2>([&](auto hc) {
+        constexpr int half = decltype(hc)::value;
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             u32x4 v[4];
@@ -481,15 +512,16 @@ __device__ __forceinline__ void load_state_rows(const FwdParams& p, size_t row0,
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(wr + (4 * grp + j) * 4 * kRowBytes + sw[j]) = v[j];
         }
-#pragma unroll
-        for (int dbl = 0; dbl < 2; ++dbl)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) oacc[2 * half + dbl][4 * g4 + e] = t[e];
-            }
-    }
+        static_for<8>([&](auto ic) {
+            constexpr int dbl = decltype(ic)::value >> 2, g4 = decltype(ic)::value & 3;
+            constexpr int i0 = 16 * (2 * half + dbl) + 4 * g4;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh));
+            acc.template put<i0>(t[0]);
+            acc.template put<i0 + 1>(t[1]);
+            acc.template put<i0 + 2>(t[2]);
+            acc.template put<i0 + 3>(t[3]);
+        });
+    });
     m_run = mx * 1.44269504088896340736f;
     m_true = m_run;
     l_run = hh == 0 ? sm : 0.0f;

@@ -55,16 +55,6 @@ struct RowState {
     float m_run, m_true, l_run;
 };
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ...
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 // ---------------------------------------------------------------------------------------------
 // The O^T accumulators are OWNED by the inline asm below: sub-block A in a[0:63], sub-block B in
 // a[64:127] (block db of 32 output columns in 16 consecutive registers); so are the Q fragments
@@ -186,7 +176,18 @@ __device__ __forceinline__ void q_install(const char* img_half, int lane) {
     q_install_issue<QBASE>(img_half, lane);
     lds_wait_all();
 }
-// whole sub-block accumulator <-> values (item boundaries only)
+// A sub-block's accumulator for the row-wise helpers (ArrayAcc's interface): no copy in architectural registers
+// (64 fewer live at the item boundaries: the kernel's register count falls from 252 to 216; bit-identical
+// results).  Whole tiles only: in the RAGGED forms the same change made the compiler keep scalars in vector
+// lanes inside the tile loop (1 - 3 % slower at L = 16383), so those still copy the accumulator out.
+template <int BASE>
+struct OwnedAcc {
+    template <int I>
+    __device__ __forceinline__ float get() const { return acc_get<BASE + I>(); }
+    template <int I>
+    __device__ __forceinline__ void put(float x) const { acc_put<BASE + I>(x); }
+};
+// whole sub-block accumulator <-> values
 template <int BASE>
 __device__ __forceinline__ void acc_load(f32x16 (&o)[4]) {
     acc_fence();
@@ -748,10 +749,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     first_scores<kQregA>(w, kb0, kb1, sa0, sa1, mx_a, c);
     if constexpr (MASKED)
         if (needs_mask(0, lim)) apply_mask(sa0, sa1, mx_a, 0, lim);
-    {
+    if constexpr (RAGGED) {
         f32x16 o[4];
         if (p.flags & kFlagLoadState)  // (sub-block A's half of the image is free: its Q fragments are installed)
-            load_state_rows(p, wrow, img, lane, o, ra.m_run, ra.m_true, ra.l_run);
+            load_state_rows(p, wrow, img, lane, ArrayAcc{o}, ra.m_run, ra.m_true, ra.l_run);
         else
             init_state(p, 0, g.hh, o, ra.m_run, ra.m_true, ra.l_run);
         acc_store<kAccA>(o);
@@ -760,8 +761,19 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[db][e] = 0.0f;
         acc_store<kAccB>(o);
+        need_a = rescale_needed(mx_a, ra.m_run);
+    } else {
+        if (p.flags & kFlagLoadState) {
+            load_state_rows(p, wrow, img, lane, OwnedAcc<kAccA>{}, ra.m_run, ra.m_true, ra.l_run);
+            need_a = rescale_needed(mx_a, ra.m_run);
+        } else {  // a fresh item takes its first tile's row max as reference at once
+            acc_zero<kAccA>();
+            ra.m_run = ra.m_true = mx_a;
+            ra.l_run = 0.0f;
+        }
+        acc_zero<kAccB>();
     }
-    rescale_if_needed<kAccA>(rescale_needed(mx_a, ra.m_run), mx_a, ra);
+    rescale_if_needed<kAccA>(need_a, mx_a, ra);
 #pragma unroll
     for (int i = 0; i < 4; ++i) pb[i] = half8{};
     rb.m_run = rb.m_true = -1e30f;
@@ -777,29 +789,49 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     size_t out_b = kNoRows;
     [[maybe_unused]] int skip_b = 0;  // rows_skipped() of the item out_b names
 
+#ifdef FA_ABLATE_NO_WRITEOUT  // (timing experiments only: wrong results)
+#define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_) do { } while (0)
+#else
 #define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_)                                     \
     do {                                                                                       \
         if ((row_) != kNoRows) {                                                               \
             const size_t r_ = (row_) + (off_);                                                 \
-            f32x16 o_[4];                                                                      \
-            acc_load<base_>(o_);                                                               \
-            if (p.flags & kFlagStoreState)                                                     \
-                store_state_rows(p, r_, (img_), lane, o_, (st_).m_run, (st_).m_true, (st_).l_run, \
-                                 RAGGED ? (skip_) - (int)(off_) : 0);                          \
-            else                                                                               \
-                store_output_rows(p.o + r_ * kHeadDim, (img_), lane, o_, (st_).l_run,          \
-                                  RAGGED ? (skip_) - (int)(off_) : 0);                         \
+            if constexpr (RAGGED) {                                                            \
+                f32x16 o_[4];                                                                  \
+                acc_load<base_>(o_);                                                           \
+                if (p.flags & kFlagStoreState)                                                 \
+                    store_state_rows(p, r_, (img_), lane, ArrayAcc{o_}, (st_).m_run, (st_).m_true, \
+                                     (st_).l_run, (skip_) - (int)(off_));                      \
+                else                                                                           \
+                    store_output_rows(p.o + r_ * kHeadDim, (img_), lane, o_, (st_).l_run,      \
+                                      (skip_) - (int)(off_));                                  \
+            } else {                                                                           \
+                acc_fence();                                                                   \
+                if (p.flags & kFlagStoreState)                                                 \
+                    store_state_rows(p, r_, (img_), lane, OwnedAcc<base_>{}, (st_).m_run, (st_).m_true, \
+                                     (st_).l_run, 0);                                          \
+                else                                                                           \
+                    store_output_rows_acc(p.o + r_ * kHeadDim, (img_), lane, OwnedAcc<base_>{}, \
+                                          (st_).l_run, 0);                                     \
+            }                                                                                  \
         }                                                                                      \
     } while (0)
+#endif
     // Start of an item for one sub-block, given the scaled row max mx_ of its first tile.  A fresh item
     // takes that max as its reference at once (nothing to rescale: O = 0, l = 0); a continued one
     // (blockwise mode) loads its state and decides as for any other tile.  Sets need_ accordingly.
 #define W64_INIT(base_, st_, row_, mx_, need_, img_)                                           \
     do {                                                                                       \
         if (p.flags & kFlagLoadState) {                                                        \
-            f32x16 o_[4];                                                                      \
-            load_state_rows(p, (row_), (img_), lane, o_, (st_).m_run, (st_).m_true, (st_).l_run); \
-            acc_store<base_>(o_);                                                              \
+            if constexpr (RAGGED) {                                                            \
+                f32x16 o_[4];                                                                  \
+                load_state_rows(p, (row_), (img_), lane, ArrayAcc{o_}, (st_).m_run, (st_).m_true, \
+                                (st_).l_run);                                                  \
+                acc_store<base_>(o_);                                                          \
+            } else {                                                                           \
+                load_state_rows(p, (row_), (img_), lane, OwnedAcc<base_>{}, (st_).m_run, (st_).m_true, \
+                                (st_).l_run);                                                  \
+            }                                                                                  \
             need_ = rescale_needed(mx_, (st_).m_run);                                          \
         } else {                                                                               \
             acc_zero<base_>();                                                                 \
@@ -847,11 +879,13 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         if (__builtin_expect(more_items && (t + 2 >= n_tiles), 0)) {
             decode(next_item, nhead, nqb);
             nwrow = source_row(nhead, nqb);
+#ifndef FA_ABLATE_NO_QDMA  // (timing experiments only: wrong results)
             if (t + 2 == n_tiles) {
                 const size_t qsrc = q_row(nhead, nqb);
                 dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
                 dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
             }
+#endif
         }
 
         // ---- phase 1: matrix side B (S_B(t), O_B += V(t-1).P_B(t-1)), vector side A
