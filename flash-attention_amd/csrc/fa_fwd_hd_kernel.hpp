@@ -524,10 +524,15 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     }
 
     wait_all_vmem();  // (the last steps' redundant transfers must not outlive the workgroup's LDS)
-    // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r in a[16db + 4g4 ..]
+    // O = acc / l: lane (r, hh) holds columns 32db + 8g4 + 4hh .. +3 of row r in a[16db + 4g4 ..].  Stored from there a
+    // wave instruction would touch 32 rows with 16 bytes each; the rows go through LDS instead (32 rows of this wave
+    // in the ring, which every wave has left: chunk c of row r at r * kRow + ((c ^ (r & kKMask)) << 4), the K tiles'
+    // swizzle) and leave as whole rows, 16 bytes per lane (measured with the stores taken out: they cost 15 - 23 % of
+    // the kernel at L <= 600 in the direct form).
     acc_fence();
     const float l_tot = half_wave_sum(l_run);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+#ifdef FA_HD_DIRECT_STORE  // (comparison builds: the direct form)
     if (MASKED ? (wave_valid && q_row0 + g.r < lq_v) : wave_valid) {
         half_t* og = p.o + srow * D;
         static_for<HD::kBlocks * 4>([&](auto ic) {
@@ -540,6 +545,55 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
             *reinterpret_cast<half4*>(og + 32 * db + 8 * g4 + 4 * g.hh) = __builtin_convertvector(v, half4);
         });
     }
+#else
+    __syncthreads();  // (every wave has read its last V tile)
+    char* st = ring + wave * (kRowsPerWave * HD::kRow);
+    // The lane id, taken from the hardware here: anything derived from the kernel's own copy is computed in front of
+    // the tile loop and kept alive through it, and the loop has no register to spare (at D = 128 the compiler then
+    // parked values in accumulator registers the MFMAs own).
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    {
+        const int r = lane_e & 31, hh = lane_e >> 5;
+        char* wr = st + r * HD::kRow + 8 * hh;
+        const int sw = (r & HD::kKMask) << 4;
+        static_for<HD::kBlocks * 4>([&](auto ic) {
+            constexpr int cidx = decltype(ic)::value;  // 4 db + g4
+            const f32x4 v = {acc_get<4 * cidx>() * inv, acc_get<4 * cidx + 1>() * inv, acc_get<4 * cidx + 2>() * inv,
+                             acc_get<4 * cidx + 3>() * inv};
+            *reinterpret_cast<half4*>(wr + ((cidx << 4) ^ sw)) = __builtin_convertvector(v, half4);
+        });
+    }
+    // (the rows are written as half4 and read back as u32x4: without this the compiler, which takes accesses of
+    // different types for independent, moved reads in front of writes)
+    asm volatile("" ::: "memory");
+    {
+        constexpr int LPR = HD::kChunks, RPI = 64 / LPR, NI = kRowsPerWave / RPI;  // lanes per row, rows per instruction
+        const int rr = lane_e / LPR, ch = lane_e % LPR;
+        // rows of this wave that exist (whole tiles: all or none)
+        const int n_rows = MASKED ? min(max(lq_v - q_row0, 0), kRowsPerWave) : (wave_valid ? kRowsPerWave : 0);
+        half_t* og = p.o + ((size_t)head * p.lq + q_row0) * D + ch * 8;
+        constexpr int GRP = NI < 4 ? NI : 4;  // reads in flight before their stores (registers: D = 128 has none to spare)
+        static_for<NI / GRP>([&](auto gc) {
+            constexpr int i0 = decltype(gc)::value * GRP;
+            u32x4 v[GRP];
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int row = (i0 + i) * RPI + rr;
+                v[i] = *reinterpret_cast<const u32x4*>(st + row * HD::kRow + ((ch ^ (row & HD::kKMask)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const int row = (i0 + i) * RPI + rr;
+#ifdef FA_HD_ABLATE_STORE  // (timing experiments only: wrong results)
+                asm volatile("" ::"v"(v[i]));
+#else
+                if (row < n_rows) __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(og + (size_t)row * D));
+#endif
+            }
+        });
+    }
+#endif
 }
 
 template <int D>

@@ -408,6 +408,8 @@ __device__ __forceinline__ void store_output_rows_acc(half_t* o_rows, char* img,
         // columns 32db + 8g4 + 4hh .. +3  =  chunk 4db+g4, second half when hh
         *reinterpret_cast<half4*>(img + stage_img_off(r, cidx) + 8 * hh) = __builtin_convertvector(t, half4);
     });
+    // (written as half4, read back as u32x4: accesses of different types, which the compiler may reorder)
+    asm volatile("" ::: "memory");
     store_staged_rows(o_rows, img, lane, first_row);
 }
 __device__ __forceinline__ void store_output_rows(half_t* o_rows, char* img, int lane, f32x16 (&oacc)[4],
@@ -473,6 +475,7 @@ __device__ __forceinline__ void store_state_rows(const FwdParams& p, size_t row0
                              acc.template get<i0 + 2>() * beta, acc.template get<i0 + 3>() * beta};
             *reinterpret_cast<f32x4*>(img + stage_img_off(r, 8 * dbl + 2 * g4 + hh)) = t;
         });
+        asm volatile("" ::: "memory");  // (f32x4 writes, u32x4 reads: keep them in this order)
         // (four rows-of-four at a time: this runs with the whole tile loop's state live)
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
@@ -512,6 +515,7 @@ __device__ __forceinline__ void load_state_rows(const FwdParams& p, size_t row0,
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(wr + (4 * grp + j) * 4 * kRowBytes + sw[j]) = v[j];
         }
+        asm volatile("" ::: "memory");  // (u32x4 writes, f32x4 reads: keep them in this order)
         static_for<8>([&](auto ic) {
             constexpr int dbl = decltype(ic)::value >> 2, g4 = decltype(ic)::value & 3;
             constexpr int i0 = 16 * (2 * half + dbl) + 4 * g4;

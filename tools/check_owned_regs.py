@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Build-time audit of fa_fwd_w64_kernel and its masked forms (causal, ragged, both) and its key-split form, whose inline asm owns the accumulator registers.
+"""Build-time audit of the kernels whose inline asm owns accumulator registers: fa_fwd_w64_kernel, its masked
+forms (causal, ragged, both) and its key-split form, and the fa_fwd_hd_kernel family.
 
-The kernel names a[0:255] literally in its instruction strings; the compiler does not know they hold
+These kernels name a[..] literally in their instruction strings; the compiler does not know they hold
 live values.  That is only sound while the compiler itself uses no accumulator register and spills
 nothing in that kernel.  This script compiles the library's device code to assembly and fails if
 any of them has scratch, spills, or any v_accvgpr_* / a[..] operand outside the #ASMSTART/#ASMEND
-blocks.
+blocks, anywhere in the function (a kernel with early exits has several s_endpgm: the scan runs to the
+function's end label).
 
     python tools/check_owned_regs.py [extra hipcc flags...]
 """
@@ -37,7 +39,8 @@ def main():
 
 
 def audit(text, KERNEL):
-    m = re.search(r"^" + KERNEL + r":.*?\n\s*s_endpgm", text, re.S | re.M)
+    # the whole function body, up to its end label (a kernel with early exits has several s_endpgm)
+    m = re.search(r"^" + KERNEL + r":.*?\n\.Lfunc_end\d+:", text, re.S | re.M)
     if not m:
         sys.exit("check_owned_regs: kernel not found in the assembly")
     problems = []
