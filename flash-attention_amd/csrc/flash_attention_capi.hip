@@ -418,10 +418,10 @@ int launch_hd_any(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) 
 // (`blockwise`: the alternative of the blockwise entry point): without the mask they win from Lq = 512 on and
 // below that with more than 128 rows in the last block; with the mask from Lq = 1088 on, from 385 on with
 // more than 128 rows in the last block, and at 192 and 256.  Against fa_fwd_hd_masked_kernel<128> (the
-// alternative everywhere else), which is 10 - 20 % faster than the general kernel: without the mask from
-// Lq = 832 on, below that with more than 128 rows in the last block; with the mask in whole tiles when the last
-// block holds more than 128 rows or from Lq = 1344 on, with ragged lengths (their form of the kernel is some
-// 15 % slower on short sequences) from Lq = 897 on when the last block holds more than 128 rows, else from 1793.
+// alternative everywhere else), which is 15 - 30 % faster than the general kernel on short sequences: without
+// the mask from Lq = 1100 on; with the mask in whole tiles from Lq = 1920 on, and from 960 on (and at 512) when
+// the last block holds at least 192 rows; with the mask and ragged lengths (their form of the kernel is some
+// 15 % slower on short sequences) from Lq = 1665 on when the last block holds more than 128 rows, else from 2305.
 // FA_MASKED_W64=1 takes them wherever they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests; see
 // Switches).
 bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false) {
@@ -434,10 +434,9 @@ bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false) {
         if (!causal) return lq >= 512 || last_block_rows > 128;
         return lq >= 1088 || (lq >= 385 && last_block_rows > 128) || lq == 192 || lq == 256;
     }
-    if (!causal) return lq >= 832 || last_block_rows > 128;
-    const bool ragged = lq % fa::kKvTile != 0;
-    if (last_block_rows > 128) return !ragged || lq >= 897;
-    return lq >= (ragged ? 1793 : 1344);
+    if (!causal) return lq >= 1100;
+    if (lq % fa::kKvTile == 0) return lq >= 1920 || (last_block_rows >= 192 && (lq >= 960 || lq == 512));
+    return lq >= (last_block_rows > 128 ? 1665 : 2305);
 }
 // (which of its instantiations: by the mask flag and by whether both lengths are whole tiles)
 const char* masked_w64_name(const fa::FwdParams& p) {

@@ -119,18 +119,19 @@ def test_masked_kernel_choice(fa, fa_env):
     general = b"fa::fa_fwd_hd_masked_kernel<128>"
     fa_env(FA_HD=None)
     fa_env(FA_MASKED_W64=None)
-    for L in (192, 256, 448, 512, 960, 1000, 1344, 1793, 16383, 16384):
+    for L in (512, 960, 1024, 1216, 1700, 1920, 2048, 2305, 16383, 16384):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
-    for L in (64, 128, 193, 320, 384, 500, 576, 640, 700, 1025, 1088, 1537):
+    for L in (64, 128, 192, 193, 256, 320, 384, 448, 500, 576, 640, 700, 768, 1000, 1025, 1088, 1344, 1537, 1793, 2049):
         assert name(L, L, 128, 1) == general
-    for Lq, Lk in ((511, 511), (2047, 2047), (193, 1000), (900, 320), (1025, 1025)):
+    for Lq, Lk in ((2047, 2047), (1100, 320), (1153, 1153), (16383, 16383)):
         assert name(Lq, Lk, 128, 0) == masked_tuned(Lq, Lk, False)
-    for Lq, Lk in ((63, 1000), (511, 191), (1, 5000), (257, 512), (100, 4000), (321, 321), (600, 320), (513, 513)):
+    for Lq, Lk in ((63, 1000), (511, 191), (1, 5000), (257, 512), (100, 4000), (321, 321), (600, 320), (513, 513), (511, 511),
+                   (193, 1000), (1025, 1025)):
         assert name(Lq, Lk, 128, 0) == general
     fa_env(FA_HD="1")  # (against the general kernel the tuned forms win earlier)
-    for L in (500, 700, 1088):
+    for L in (192, 256, 448, 500, 700, 1088):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
-    assert name(600, 320, 128, 0) == masked_tuned(600, 320, False)
+    assert name(600, 320, 128, 0) == masked_tuned(600, 320, False) and name(511, 511, 128, 0) == masked_tuned(511, 511, False)
     fa_env(FA_HD=None)
     assert name(512, 512, 64, 1) == b"fa::fa_fwd_hd_masked_kernel<64>" and name(511, 511, 256, 0) == b"fa::fa_fwd_hd_masked_kernel<256>"
     assert name(512, 512, 128, 0) == fa.lib().fa_kernel_name(512, 512)
@@ -490,9 +491,11 @@ def test_causal_zigzag_ring_on_one_gpu(fa, oracle, dev):
     gate(oracle, oracle.attention_cpu(Q, K, V, causal=True), O, "zig-zag ring on one GPU")
 
 
-def test_ring_forward_default_step_takes_any_length(fa, dev, tmp_path):
+def test_ring_forward_default_step_takes_any_length(fa, oracle, dev, tmp_path, fa_env):
     """multi_gpu.ring_forward with its default step (fa_forward_block_general) on one rank: rows per rank that are
-    not a multiple of 64 go through, and the result is that of the one-call entry point."""
+    not a multiple of 64 go through; the result is, bit for bit, that of the one-call entry point on the same kernel
+    (FA_MASKED_W64=1: at this length the one call would otherwise take the 128-row kernel), and within the gate
+    of the one call's own choice."""
     import sys
     import torch
     import torch.distributed as dist
@@ -505,9 +508,13 @@ def test_ring_forward_default_step_takes_any_length(fa, dev, tmp_path):
     try:
         Q, K, V = normal_fp16(33, (1, 4, 700, 128))
         q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+        fa_env(FA_MASKED_W64="1")
         out = mg.ring_forward(q, k, v)
         torch.cuda.synchronize()
         assert torch.equal(out, fa.attention_general(q, k, v))
+        fa_env(FA_MASKED_W64=None)
+        gate(oracle, fa.attention_general(q, k, v).cpu().numpy().astype(np.float32), out.cpu().numpy(),
+             "ring step against the one call")
     finally:
         dist.destroy_process_group()
 

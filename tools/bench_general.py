@@ -58,6 +58,8 @@ for B, L in () if "--only-sweep" in sys.argv else ((32, 512), (8, 2048), (1, 163
     run("general kernel, causal, L-1", B, L - 1, True, tuned_causal=False)
 if "--ragged-sweep" in sys.argv:
     Ls = [L for L0 in range(192, 2305, 64) for L in (L0, L0 + 1)] if "--fine" in sys.argv else (193, 257, 321, 385, 449, 511, 577, 767, 1023)
+    if "--lengths" in sys.argv:  # --lengths 2305,2561,...
+        Ls = [int(x) for x in sys.argv[sys.argv.index("--lengths") + 1].split(",")]
     for L in Ls:
         B = max(1, 16384 // L)
         for causal in (False, True):
