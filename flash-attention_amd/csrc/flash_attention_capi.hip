@@ -103,6 +103,15 @@ int pick_waves() { return switches().nwaves; }
 enum KernelId { kKernelW64, kKernelRing, kKernelStaged8, kKernelStaged4 };
 const char* const kKernelNames[] = {"fa::fa_fwd_w64_kernel", "fa::fa_fwd_ring_kernel<8>", "fa::fa_fwd_kernel<8>",
                                     "fa::fa_fwd_kernel<4>"};
+// Self-attention in whole tiles at L = 320 and 384: the second 256-row block is at most half full there, and the
+// 128-row kernel (its masked form, which takes any lengths) was measured 7 % and 13 % faster than the kernel below
+// (tools/whole_tiles_128.py; with Lq != Lk the comparison depends on how many workgroups the shape gives the
+// 128-row kernel, and those shapes stay here).  Not when FA_W64 forces a kernel, nor for calls that carry state.
+bool short_self_attention_on_hd(int lq, int lk, int flags) {
+    const Switches& sw = switches();
+    return flags == 0 && lq == lk && (lq == 320 || lq == 384) && sw.hd && sw.hd_masked && sw.nwaves == 8 &&
+           sw.w64_from == 5 * fa::kKvTile;
+}
 KernelId pick_kernel(int nw, int lq, int lk) {
     (void)lq;
     const Switches& sw = switches();
@@ -254,7 +263,11 @@ enum class Workspace {
     kScratch,  // the static per-device scratch buffer: nothing is allocated; too large a need is an error
 };
 
+template <int D>
+int launch_hd(const fa::FwdParams& base, bool masked, hipStream_t stream);
+
 int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Workspace::kNone) {
+    if (short_self_attention_on_hd(base.lq, base.lk, base.flags)) return launch_hd<128>(base, true, stream);
     fa::FwdParams p = base;
 #ifdef FA_STAMPS
     p.stamps = g_stamps;
@@ -574,15 +587,19 @@ int fa_get_reserved_cus(void) {
     (void)switches();
     return g_reserved_cus.load(std::memory_order_relaxed);
 }
-const char* fa_kernel_name(int lq, int lk) { return kKernelNames[pick_kernel(pick_waves(), lq, lk)]; }
+const char* fa_kernel_name(int lq, int lk) {
+    if (short_self_attention_on_hd(lq, lk, 0)) return "fa::fa_fwd_hd_masked_kernel<128>";
+    return kKernelNames[pick_kernel(pick_waves(), lq, lk)];
+}
 int fa_split_ways(int bh, int lq, int lk) {
     if (bh <= 0 || lq <= 0 || lk <= 0 || lq % fa::kKvTile != 0 || lk % fa::kKvTile != 0) return 1;
     if (pick_kernel(pick_waves(), lq, lk) != kKernelW64 || !switches().persistent) return 1;
+    if (short_self_attention_on_hd(lq, lk, 0)) return 1;
     return pick_split(bh, (lq + 255) / 256, lq, lk, persistent_grid(), kSplitMaxRows);
 }
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
-        case kRouteTuned: return fa_kernel_name(lq, lk);
+        case kRouteTuned: return kKernelNames[pick_kernel(pick_waves(), lq, lk)];  // (a call that carries state)
         case kRouteUnmaskedRaggedW64: return "fa::fa_fwd_w64_ragged_kernel";
         case kRouteMaskedW64: {
             fa::FwdParams p{};

@@ -698,3 +698,31 @@ def test_other_head_dims_causal_many_blocks(fa, oracle, dev, D, fa_env):
     # (the first rows of a causal sequence average few values: |O| reaches 2 to 4 there, where fp16 neighbours lie
     # 2e-3 apart, so the absolute bound scales with |O| above 1)
     assert m["max_abs"] <= MAX_ABS_TOL * max(1.0, float(np.abs(ref).max())) and m["global_rel"] <= REL_L2_TOL, m
+
+
+@pytest.mark.parametrize("L", [320, 384])
+def test_short_self_attention_takes_the_128_row_kernel(fa, oracle, dev, L, fa_env):
+    """Lq = Lk = 320 / 384 in whole tiles: the drop-in entry point's launcher hands these two lengths to the 128-row
+    kernel (the second 256-row block would be at most half full); FA_HD=1 and FA_W64 keep them on the 256-row kernels,
+    as do calls with Lq != Lk."""
+    import torch
+
+    fa_env(FA_HD=None, FA_W64=None)
+    name = fa.lib().fa_kernel_name
+    assert name(L, L) == b"fa::fa_fwd_hd_masked_kernel<128>" == fa.lib().fa_kernel_name_general(L, L, 128, 0)
+    assert name(L, L + 64) == b"fa::fa_fwd_w64_kernel" and name(448, 448) == b"fa::fa_fwd_w64_kernel"
+    assert fa.lib().fa_split_ways(2, L, L) == 1
+    Q, K, V = normal_fp16(7000 + L, (2, 3, L, 128))
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = torch.full_like(q, float("nan"))
+    fa.attention(q, k, v, out=o)
+    torch.cuda.synchronize()
+    ref = oracle.attention_cpu(Q, K, V)
+    gate(oracle, ref, o.cpu().numpy(), f"L={L} on the 128-row kernel")
+    fa_env(FA_HD="1")
+    assert name(L, L) == b"fa::fa_fwd_w64_kernel"
+    o2 = fa.attention(q, k, v)
+    torch.cuda.synchronize()
+    gate(oracle, ref, o2.cpu().numpy(), f"L={L} on the 256-row kernel")
+    fa_env(FA_HD=None, FA_W64="1")
+    assert name(L, L) == b"fa::fa_fwd_w64_kernel"

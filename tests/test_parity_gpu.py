@@ -125,8 +125,10 @@ def test_every_kernel_variant(fa, oracle, torch_dev, env, kernel, fa_env, reques
 
 def test_default_kernel_choice(fa):
     name = fa.lib().fa_kernel_name
-    assert name(512, 512) == name(16384, 16384) == name(320, 320) == name(1984, 1984) == b"fa::fa_fwd_w64_kernel"
+    assert name(512, 512) == name(16384, 16384) == name(320, 384) == name(448, 448) == name(1984, 1984) == b"fa::fa_fwd_w64_kernel"
     assert name(64, 64) == name(256, 256) == name(512, 256) == b"fa::fa_fwd_ring_kernel<8>"
+    # (self-attention at 320 and 384: the second 256-row block would be at most half full)
+    assert name(320, 320) == name(384, 384) == b"fa::fa_fwd_hd_masked_kernel<128>"
 
 
 def test_result_does_not_depend_on_what_ran_before(fa, oracle, torch_dev):
