@@ -276,6 +276,35 @@ __device__ __forceinline__ void hd_mask_scores(f32x16 (&s)[KB], int thr_minus_4h
         }
 }
 
+// A block of which this workgroup sees no key (blockwise mode): the carried state goes through as it is, to the
+// state arrays again or, on the last block, normalised to O.  Lane (r, hh) holds columns 8c + 4hh .. + 3 of its row.
+template <int D>
+__device__ __forceinline__ void hd_pass_state(const FwdParams& p, size_t srow, int hh, bool row_valid, bool load,
+                                              bool store) {
+    if (!row_valid) return;
+    if (load && store) return;  // in and out are the same arrays
+    if (store) {  // a first block without keys: the empty state
+        if (hh == 0) {
+            p.row_max[srow] = -1e30f * 0.69314718055994530942f;
+            p.row_sum[srow] = 0.0f;
+        }
+        float* oa = p.o_acc + srow * D;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) *reinterpret_cast<f32x4*>(oa + 8 * c + 4 * hh) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
+    // the last block: O = o_acc / row_sum (0 for a row that has seen no key at all)
+    const float l = p.row_sum[srow];
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    const float* oa = p.o_acc + srow * D;
+    half_t* og = p.o + srow * D;
+#pragma unroll
+    for (int c = 0; c < D / 8; ++c) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(oa + 8 * c + 4 * hh);
+        *reinterpret_cast<half4*>(og + 8 * c + 4 * hh) = __builtin_convertvector(t * inv, half4);
+    }
+}
+
 // MASKED = false: whole tiles, no mask (lq % 32 == 0, lk % TK == 0).  MASKED = true adds, outside the two blocks,
 //   * any lq >= 1: query rows past the end are computed on a copy of the last row and not stored;
 //   * any lk >= 0: the rows of the last tile that lie past the last key are fetched from the last key's row (finite
@@ -284,8 +313,12 @@ __device__ __forceinline__ void hd_mask_scores(f32x16 (&s)[KB], int thr_minus_4h
 //     workgroup stops at the tile that holds its last row's diagonal, the long query blocks are handed out first;
 //   * padded batches: per-sequence lengths q_len[b], k_len[b] (device arrays) in place of lq, lk, which stay the strides.
 // A tile that the diagonal or the sequence's end touches gets hd_mask_scores() in a cold branch between the blocks.
-template <int D, bool MASKED>
+// STATE (with MASKED) adds blockwise mode, as in the other kernels (kFlagLoadState / kFlagStoreState: the carried
+// (o_acc, row_max, row_sum) of every row in, or out instead of O) with the mask on absolute positions q_pos0 + i,
+// k_pos0 + j: a row may then see no key of the block at all, and its carried state passes through unchanged.
+template <int D, bool MASKED, bool STATE = false>
 __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
+    static_assert(!STATE || MASKED, "blockwise mode is built on the masked form");
     using HD = HeadDim<D>;
     using CFG = HdCfg<D>;
     constexpr int NWAVES = CFG::kWaves, TK = CFG::kTk, STAGES = CFG::kStages, KB = TK / 32;
@@ -307,6 +340,9 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     int head, qb;
     decode_item(p, (int)blockIdx.x, head, qb);
     [[maybe_unused]] const bool causal = MASKED && (p.flags & kFlagCausal) != 0;
+    [[maybe_unused]] const int shift = STATE ? p.q_pos0 - p.k_pos0 : 0;  // keys are counted from this block's first
+    [[maybe_unused]] const bool load_state = STATE && (p.flags & kFlagLoadState) != 0;
+    [[maybe_unused]] const bool store_state = STATE && (p.flags & kFlagStoreState) != 0;
     int lq_v = p.lq, lk_v = p.lk;  // this sequence's valid rows and keys
     if constexpr (MASKED) {
         if (causal) qb = p.q_blocks - 1 - qb;  // block qb costs qb + 1 units: the long ones first
@@ -327,8 +363,14 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     [[maybe_unused]] const int last_key_tile = n_tiles - 1;          // the tile the sequence's end may cut
     [[maybe_unused]] const bool ragged_end = MASKED && lk_v % TK != 0;
     if constexpr (MASKED) {
-        if (causal) n_tiles = min(n_tiles, (min(qb * QB + QB, lq_v) + TK - 1) / TK);
-        if (n_tiles == 0) {  // no keys: O = 0
+        if (causal) n_tiles = max(0, min(n_tiles, (min(qb * QB + QB, lq_v) + shift + TK - 1) / TK));
+        if (n_tiles == 0) {  // no keys: O = 0, or the carried state as it is
+            if constexpr (STATE) {
+                if (load_state || store_state) {
+                    hd_pass_state<D>(p, srow, g.hh, wave_valid && q_row0 + g.r < lq_v, load_state, store_state);
+                    return;
+                }
+            }
             if (wave_valid && q_row0 + g.r < lq_v) {
                 half_t* og = p.o + srow * D;
 #pragma unroll
@@ -338,9 +380,9 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         }
     }
     // last key this lane's row may see, and whether tile `tile` needs the mask for this wave (wave-uniform)
-    [[maybe_unused]] const int key_limit = causal ? min(lk_v - 1, q_abs) : lk_v - 1;
+    [[maybe_unused]] const int key_limit = causal ? min(lk_v - 1, q_abs + shift) : lk_v - 1;
     [[maybe_unused]] auto needs_mask = [&](int tile) -> bool {
-        return (ragged_end && tile == last_key_tile) || (causal && tile * TK + TK - 1 > q_row0);
+        return (ragged_end && tile == last_key_tile) || (causal && tile * TK + TK - 1 > q_row0 + shift);
     };
 
     // ---- DMA geometry: this wave moves pieces PPW*wave .. PPW*wave + PPW - 1 of the K tile and of the V tile, i.e.
@@ -431,6 +473,35 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     if constexpr (MASKED)
         if (needs_mask(0)) hd_mask_scores<KB>(s_cur, key_limit - 4 * g.hh);
     float m_run = hd_row_max<KB>(s_cur, c);
+    [[maybe_unused]] float m_true = m_run;  // (STATE: the state goes out relative to the true running max)
+    if constexpr (STATE) {
+        // a row that sees nothing of tile 0 sees nothing of the block: keep its reference finite
+        m_run = fmaxf(m_run, -1e30f);
+        m_true = m_run;
+        if (load_state) {
+            const float mx0 = m_run;
+            m_run = p.row_max[srow] * 1.44269504088896340736f;
+            l_run = g.hh == 0 ? p.row_sum[srow] : 0.0f;
+            const float* oa = p.o_acc + srow * D;
+            acc_fence();
+            static_for<HD::kBlocks * 4>([&](auto ic) {
+                constexpr int cidx = decltype(ic)::value;  // 4 db + g4
+                const f32x4 t = *reinterpret_cast<const f32x4*>(oa + 8 * cidx + 4 * g.hh);
+                acc_put<4 * cidx>(t[0]);
+                acc_put<4 * cidx + 1>(t[1]);
+                acc_put<4 * cidx + 2>(t[2]);
+                acc_put<4 * cidx + 3>(t[3]);
+            });
+            m_true = fmaxf(m_run, mx0);
+            if (!__all(mx0 - m_run <= kRescaleSlack)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_true);
+                m_run = m_true;
+                l_run *= alpha;
+                acc_scale_n<0, 16 * HD::kBlocks>(alpha);
+            }
+            wait_all_vmem();  // (the loop counts its own transfers by hand: nothing else may be in flight)
+        }
+    }
 
     // One step per tile.  The loop below is STAGES copies of it, one per ring stage, so that every stage offset is a
     // compile-time constant and the LDS reads take it as their immediate offset (with a run-time stage every read
@@ -490,6 +561,7 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
                     hd_mask_scores<KB>(s_next, key_limit - (t + 1) * TK - 4 * g.hh);
                 }
             hd_block2<D, KB, true>(ring + ST * kStage + kTile, g, pf, s_next, c, mx);
+            if constexpr (STATE) m_true = fmaxf(m_true, mx);
             if (__builtin_expect(!__all(mx - m_run <= kRescaleSlack), 0)) {
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -530,6 +602,27 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     // swizzle) and leave as whole rows, 16 bytes per lane (measured with the stores taken out: they cost 15 - 23 % of
     // the kernel at L <= 600 in the direct form).
     acc_fence();
+    if constexpr (STATE) {
+        if (store_state) {
+            // the state relative to the true running max, whatever reference was in use
+            const float beta = __builtin_amdgcn_exp2f(m_run - m_true);
+            const float l_sum = half_wave_sum(l_run) * beta;
+            if (wave_valid && q_row0 + g.r < lq_v) {
+                if (g.hh == 0) {
+                    p.row_max[srow] = m_true * 0.69314718055994530942f;
+                    p.row_sum[srow] = l_sum;
+                }
+                float* oa = p.o_acc + srow * D;
+                static_for<HD::kBlocks * 4>([&](auto ic) {
+                    constexpr int cidx = decltype(ic)::value;
+                    const f32x4 t = {acc_get<4 * cidx>() * beta, acc_get<4 * cidx + 1>() * beta,
+                                     acc_get<4 * cidx + 2>() * beta, acc_get<4 * cidx + 3>() * beta};
+                    *reinterpret_cast<f32x4*>(oa + 8 * cidx + 4 * g.hh) = t;
+                });
+            }
+            return;
+        }
+    }
     const float l_tot = half_wave_sum(l_run);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
 #ifdef FA_HD_DIRECT_STORE  // (comparison builds: the direct form)
@@ -604,6 +697,11 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
 template <int D>
 __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_masked_kernel(const FwdParams p) {
     fa_fwd_hd_body<D, true>(p);
+}
+// The masked form in blockwise mode: carried state in and / or out, the mask on absolute positions.
+template <int D>
+__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_state_kernel(const FwdParams p) {
+    fa_fwd_hd_body<D, true, true>(p);
 }
 
 }  // namespace fa

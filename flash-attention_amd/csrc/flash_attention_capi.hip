@@ -418,6 +418,26 @@ int launch_hd(const fa::FwdParams& base, bool masked, hipStream_t stream) {
     FA_HIP(hipGetLastError());
     return FA_OK;
 }
+// Blockwise mode on the same kernel family (carried state, absolute positions): every block at D = 64 / 256.
+// FA_HD=0 / 1 keeps these on the general kernel.  (D = 128: the blocks that the tuned kernels do not take stay on
+// the general kernel; this form at D = 128, two workgroups per CU, has no register left for the carried state.)
+bool block_on_hd(int D) { return (D == 64 || D == 256) && switches().hd && switches().hd_masked; }
+template <int D>
+int launch_hd_state(const fa::FwdParams& base, hipStream_t stream) {
+    fa::FwdParams p = base;
+    constexpr int kBlockRows = fa::HdCfg<D>::kWaves * fa::kRowsPerWave;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
+    p.q_blocks = (p.lq + kBlockRows - 1) / kBlockRows;
+    const long items = (long)p.bh * p.q_blocks;
+    if (items <= 0 || items > 0x7fffffffL) return fail(FA_ERR_SHAPE, "grid size out of range%s");
+    hipLaunchKernelGGL(fa::fa_fwd_hd_state_kernel<D>, dim3((unsigned)items), dim3(fa::HdCfg<D>::kWaves * 64), 0, stream, p);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+int launch_block_other(const fa::FwdParams& p, int D, hipStream_t stream) {
+    if (!block_on_hd(D)) return launch_general(p, D, stream);
+    return D == 64 ? launch_hd_state<64>(p, stream) : launch_hd_state<256>(p, stream);
+}
 int launch_hd_any(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) {
     if (D == 128) return launch_hd<128>(p, true, stream);
     return D == 64 ? launch_hd<64>(p, r == kHdMasked, stream) : launch_hd<256>(p, r == kHdMasked, stream);
@@ -606,7 +626,9 @@ const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q
             p.lq = lq, p.lk = lk, p.flags = fa::kFlagCausal;
             return masked_w64_name(p);
         }
-        default: return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
+        default:
+            if (block_on_hd(D)) return D == 64 ? "fa::fa_fwd_hd_state_kernel<64>" : "fa::fa_fwd_hd_state_kernel<256>";
+            return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
     }
 }
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
@@ -762,7 +784,7 @@ int fa_forward_block_general(const uint16_t* dQ, const uint16_t* dK, const uint1
         case kRouteMaskedW64:
             return launch_w64_masked(p, stream);
         default:
-            return launch_general(p, D, stream);
+            return launch_block_other(p, D, stream);
     }
 }
 

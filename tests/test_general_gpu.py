@@ -323,7 +323,7 @@ def test_sibling_library_symbols(fa, oracle):
         gate(oracle, oracle.attention_cpu(Q, K, V, causal=True) if call == "naive_causal" else ref, O, call)
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
 def test_blockwise_general_blocks_in_any_order(fa, oracle, dev, D):
     """fa_forward_block_general: a causal sequence folded from K/V blocks of unequal, ragged sizes in
     shuffled order, absolute positions given per block; rows that see nothing of a block keep their
@@ -362,7 +362,7 @@ def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, d
     assert name(512, 512, 128, 1, 512, 256) == general          # crossed by the diagonal elsewhere
     assert name(512, 512, 128, 0, 0, 0) == tuned
     assert name(512, 100, 128, 0, 0, 0) == general and name(100, 512, 128, 1, 1536, 0) == general
-    assert name(512, 512, 64, 0, 0, 0) == b"fa::fa_fwd_general_kernel<64>"
+    assert name(512, 512, 64, 0, 0, 0) == b"fa::fa_fwd_hd_state_kernel<64>"
 
     B, H, L = 1, 5, 3 * 512 + 100
     Q, K, V = normal_fp16(77, (B, H, L, 128))
@@ -726,3 +726,65 @@ def test_short_self_attention_takes_the_128_row_kernel(fa, oracle, dev, L, fa_en
     gate(oracle, ref, o2.cpu().numpy(), f"L={L} on the 256-row kernel")
     fa_env(FA_HD=None, FA_W64="1")
     assert name(L, L) == b"fa::fa_fwd_w64_kernel"
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("D", [64, 256])
+def test_blockwise_other_head_dims_on_the_pipelined_kernel(fa, oracle, dev, D, causal, fa_env):
+    """fa_forward_block_general at D = 64 / 256 runs on fa_fwd_hd_state_kernel<D> (FA_HD=0: the general kernel): a
+    query chunk that starts in the middle of a sequence (q_pos0 = 500) folded over four key chunks of several
+    tiles each in shuffled order: one wholly before it, one that its diagonal crosses, one whose first keys only
+    the last rows see, one wholly behind it (with the mask: the carried state passes through unchanged).  The
+    output against the oracle over the whole sequence, on this kernel and on the general kernel."""
+    import torch
+
+    fa_env(FA_HD=None)
+    BH, L = 3, 1200
+    Q, K, V = normal_fp16(5000 + D, (1, BH, L, D))
+    q0, nq = 500, 300
+    cuts = [0, 448, 700, 1000, 1200]
+    order = [3, 1, 0, 2] if causal else [2, 0, 3, 1]
+    qc = torch.from_numpy(np.ascontiguousarray(Q[:, :, q0:q0 + nq])).to(dev)
+    name = fa.lib().fa_kernel_name_block_general
+    assert name(nq, 252, D, int(causal), q0, 448) == f"fa::fa_fwd_hd_state_kernel<{D}>".encode()
+    outs = {}
+    for hd in (None, "0"):
+        fa_env(FA_HD=hd)
+        st = fa.BlockState(BH, nq, D, dev)
+        out = None
+        for n, c in enumerate(order):
+            a, b = cuts[c], cuts[c + 1]
+            kc, vc = [torch.from_numpy(np.ascontiguousarray(x[:, :, a:b])).to(dev) for x in (K, V)]
+            out = fa.attention_block_general(qc, kc, vc, st, last=(n == len(order) - 1), causal=causal, q_pos0=q0, k_pos0=a)
+        torch.cuda.synchronize()
+        outs[hd] = out.cpu().numpy()
+    if causal:
+        ref = oracle.attention_cpu(Q, K, V, causal=True)[:, :, q0:q0 + nq]
+    else:
+        ref_st = oracle.BlockState(1, BH, nq, D)
+        oracle.block_update(ref_st, np.ascontiguousarray(Q[:, :, q0:q0 + nq]), K, V)
+        ref = oracle.block_finalize(ref_st)
+    gate(oracle, ref, outs[None], f"blockwise D={D} causal={causal} on the pipelined kernel")
+    gate(oracle, ref, outs["0"], f"blockwise D={D} causal={causal} on the general kernel")
+
+
+@pytest.mark.parametrize("D", [64, 256])
+def test_blockwise_other_head_dims_state_values(fa, oracle, dev, D):
+    """The carried state itself after a first block (no mask): row_max is the true row maximum in natural-log units,
+    row_sum and o_acc the sums relative to it, as the oracle's block_update leaves them."""
+    import torch
+
+    BH, Lq, Lk = 2, 200, 333
+    Q = normal_fp16(6000 + D, (1, BH, Lq, D))[0]
+    K, V = normal_fp16(6100 + D, (1, BH, Lk, D))[:2]
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    st = fa.BlockState(BH, Lq, D, dev)
+    fa.attention_block_general(q, k, v, st, last=False)
+    torch.cuda.synchronize()
+    ref = oracle.BlockState(1, BH, Lq, D)
+    oracle.block_update(ref, Q, K, V)
+    m_ref, l_ref, o_ref = [np.asarray(x, dtype=np.float64).reshape(BH * Lq, -1) for x in (ref.mx, ref.sm, ref.acc)]
+    m, l, o = [x.cpu().numpy().astype(np.float64).reshape(BH * Lq, -1) for x in (st.row_max, st.row_sum, st.o_acc)]
+    assert np.abs(m - m_ref).max() <= 1e-5 * max(1.0, np.abs(m_ref).max())
+    assert np.abs(l / l_ref - 1).max() <= 2e-3
+    assert np.abs(o - o_ref).max() <= 2e-3 * max(1.0, np.abs(o_ref).max())
