@@ -190,7 +190,11 @@ __device__ __forceinline__ void hd_block1(const char* kb, const LaneGeomD<D>& g,
                 mfma_vv_first(s_next[b], kf[gi % KA], qf[ks]);
             else
                 mfma_vv(s_next[b], kf[gi % KA], qf[ks]);
+#ifdef FA_HD_ABLATE_LDS  // (timing experiment only: every second fragment read is left out; wrong results)
+            if constexpr (gi + KA < NS && (gi & 1) == 0) kf[gi % KA] = k_frag(std::integral_constant<int, gi + KA>{});
+#else
             if constexpr (gi + KA < NS) kf[gi % KA] = k_frag(std::integral_constant<int, gi + KA>{});
+#endif
             constexpr int every = NS / NDMA;
             if constexpr (gi % every == every - 1) dma(std::integral_constant<int, gi / every>{});
         }
@@ -239,7 +243,11 @@ __device__ __forceinline__ void hd_block2(const char* vb, const LaneGeomD<D>& g,
     static_for<NP>([&](auto ic) {
         constexpr int gi = decltype(ic)::value, kk = gi / HD::kBlocks, db = gi % HD::kBlocks;
         mfma_acc<16 * db>(vf[gi % VA], pf[kk]);
+#ifdef FA_HD_ABLATE_LDS
+        if constexpr (gi + VA < NP && (gi & 1) == 0) vf[gi % VA] = hd_read_v<D, KB>(vb, g, gi + VA);
+#else
         if constexpr (gi + VA < NP) vf[gi % VA] = hd_read_v<D, KB>(vb, g, gi + VA);
+#endif
 #ifdef FA_HD_ABLATE_MAX
         if constexpr (false) {
 #else
