@@ -9,7 +9,9 @@ bit; the 8-wave ring kernel (FA_W64=0) and the register-staged kernel (FA_W64=0 
 same arithmetic in the same order per row and must agree bit for bit with each other; the
 one-wave-per-SIMD kernel adds a row's exponentials in a different order, so it may differ from them
 by the rounding of the result (one fp16 ulp).  Anything else is a scheduling, synchronisation or
-initialisation fault.
+initialisation fault.  The launcher's key split (few heads on a long sequence: FA_SPLIT unset) folds
+partial sums of key ranges, another arithmetic again: it is run beside the undivided launch
+(FA_SPLIT=1) and held to a bound relative to the row's largest output.
 
     python tools/fuzz_kernels.py --causal [--iters 300]
 
@@ -35,7 +37,8 @@ if not args.causal:  # the register-staged kernel (FA_RING=0) lives in the compa
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(args.seed)
 cpu = torch.Generator().manual_seed(args.seed)
-envs = [{"FA_W64": "1"}, {"FA_W64": "0"}, {"FA_W64": "0", "FA_RING": "0"}]  # (FA_W64=1: from three tiles on)
+# (FA_W64=1: from three tiles on; FA_SPLIT=1: never divide the keys; the last one is the launcher's own choice)
+envs = [{"FA_W64": "1", "FA_SPLIT": "1"}, {"FA_W64": "0"}, {"FA_W64": "0", "FA_RING": "0"}, {"FA_W64": "1"}]
 
 if args.causal:
     envs = [{"FA_MASKED_W64": "1"}, {"FA_MASKED_W64": "0", "FA_HD": "1"}, {"FA_MASKED_W64": "0"}]
@@ -91,7 +94,10 @@ for it in range(args.iters):
         close = close and bool(((a - c).abs() <= 2.0 ** -9 * row + 1e-6).all())
         same = all(torch.equal(outs[i], outs[i + 1]) for i in (0, 2, 4))
     else:
-        same = torch.equal(outs[0], outs[1]) and all(torch.equal(outs[2], o) for o in outs[3:])
+        same = torch.equal(outs[0], outs[1]) and all(torch.equal(outs[2], o) for o in outs[3:6]) and torch.equal(outs[6], outs[7])
+        c = outs[6].float()  # (the key split, where the launcher chooses it)
+        row = torch.maximum(a.abs(), c.abs()).amax(dim=-1, keepdim=True)
+        close = close and bool(((a - c).abs() <= 2.0 ** -9 * row + 1e-6).all())
     ok = same and close and bool(torch.isfinite(a).all())
     if not ok:
         bad += 1
