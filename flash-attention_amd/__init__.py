@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "fa_kernel_name_general",
     "fa_kernel_name_block_general",
     "fa_split_ways",
+    "fa_split_ways_general",
     "fa_set_reserved_cus",
     "fa_get_reserved_cus",
     "fa_debug_reload_env",
@@ -124,6 +125,8 @@ def bind(path: str) -> ct.CDLL:
     L.fa_kernel_name_block_general.restype = ct.c_char_p
     L.fa_split_ways.argtypes = [ct.c_int] * 3
     L.fa_split_ways.restype = ct.c_int
+    L.fa_split_ways_general.argtypes = [ct.c_int] * 5
+    L.fa_split_ways_general.restype = ct.c_int
     L.fa_set_reserved_cus.argtypes = [ct.c_int]
     L.fa_set_reserved_cus.restype = ct.c_int
     L.fa_get_reserved_cus.argtypes = []

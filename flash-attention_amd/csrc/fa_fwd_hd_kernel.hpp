@@ -361,6 +361,20 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         }
         if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
     }
+    // Key ranges (STATE, p.k_splits > 1; the launcher's split for shapes with few workgroups, such as a handful of
+    // query rows against a long sequence): head `head` of the p.bh is range head / bh_real of real head
+    // head % bh_real; it reads that head's Q rows and keys [key_first, key_first + lk_v) and stores its state under
+    // its own (virtual) head.
+    [[maybe_unused]] int head_q = head;
+    [[maybe_unused]] size_t key_first = 0;
+    if constexpr (STATE) {
+        if (p.k_splits > 1) {
+            const int range = head / p.bh_real;
+            head_q = head - range * p.bh_real;
+            key_first = (size_t)range * p.lk_split;
+            lk_v = min(p.lk_split, p.lk - range * p.lk_split);
+        }
+    }
     const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
     const bool wave_valid = q_row0 < lq_v;              // a wave past the last row computes along and stores nothing
     // this lane's query row: past the end, the last row (MASKED) or the block's first rows (whole tiles)
@@ -407,8 +421,8 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         d_voff[j] = rowoff + (unsigned)((d_slot ^ ((row & HD::kVMask) << 2)) << 4);
     }
     const unsigned d_lds = ring_lds + (unsigned)(PPW * wave) * 1024u;
-    const half_t* kh = p.k + (size_t)head * p.lk * D;
-    const half_t* vh = p.v + (size_t)head * p.lk * D;
+    const half_t* kh = p.k + ((size_t)(STATE ? head_q : head) * p.lk + (STATE ? key_first : 0)) * D;
+    const half_t* vh = p.v + ((size_t)(STATE ? head_q : head) * p.lk + (STATE ? key_first : 0)) * D;
     // MASKED: the same offsets for the tile the sequence's end cuts, with every row past the last key replaced by the
     // last key's row.  (The instruction's immediate offset 1024 j is added on both sides, so it is taken off here.)
     [[maybe_unused]] unsigned d_koff_end[PPW], d_voff_end[PPW];
@@ -460,7 +474,7 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     });
     half8 qf[HD::kSteps];
     {
-        const half_t* qr = p.q + srow * D + g.hh * 8;
+        const half_t* qr = p.q + (STATE ? (size_t)head_q * p.lq + q_abs : srow) * D + g.hh * 8;
 #pragma unroll
         for (int ks = 0; ks < HD::kSteps; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qr + ks * 16);
     }
@@ -707,9 +721,39 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_
     fa_fwd_hd_body<D, true>(p);
 }
 // The masked form in blockwise mode: carried state in and / or out, the mask on absolute positions.
+// (D = 128: compiled for one workgroup per CU: with the register budget of two the carried state did not fit, and
+// the compiler parked values in accumulator registers the MFMAs own; how many workgroups share a CU is decided by
+// what the kernel then uses.)
 template <int D>
-__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, HdCfg<D>::kOcc) void fa_fwd_hd_state_kernel(const FwdParams p) {
+__global__ __launch_bounds__(HdCfg<D>::kWaves * 64, D == 128 ? 1 : HdCfg<D>::kOcc) void fa_fwd_hd_state_kernel(const FwdParams p) {
     fa_fwd_hd_body<D, true, true>(p);
+}
+
+// Folds the key ranges of a split launch of fa_fwd_hd_state_kernel<D> (fa_split_merge_kernel for any head dim): row i
+// of the output is  O[i] = sum_s w_s o_s[i] / sum_s w_s l_s[i],  w_s = exp(m_s[i] - max_s m_s[i])  (o_s, m_s, l_s: row
+// s * rows + i of the state arrays).  D / 4 lanes per row, four columns each.
+template <int D>
+__global__ __launch_bounds__(256) void fa_hd_split_merge_kernel(const float* __restrict__ o_acc, const float* __restrict__ row_max,
+                                                                const float* __restrict__ row_sum, half_t* __restrict__ o,
+                                                                size_t rows, int n_ranges) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    const int c = threadIdx.x % LPR;
+    const size_t per_pass = (size_t)gridDim.x * RPB;
+    for (size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR; i < rows; i += per_pass) {
+        float m = -__builtin_inff();
+        for (int s = 0; s < n_ranges; ++s) m = fmaxf(m, row_max[(size_t)s * rows + i]);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        float l = 0.0f;
+        for (int s = 0; s < n_ranges; ++s) {
+            const size_t r = (size_t)s * rows + i;
+            const float w = __expf(row_max[r] - m);
+            l += w * row_sum[r];
+            const f32x4 t = *(reinterpret_cast<const f32x4*>(o_acc + r * D) + c);
+            acc += t * w;
+        }
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        *(reinterpret_cast<half4*>(o + i * D) + c) = __builtin_convertvector(acc * inv, half4);
+    }
 }
 
 }  // namespace fa

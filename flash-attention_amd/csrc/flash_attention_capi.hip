@@ -418,10 +418,9 @@ int launch_hd(const fa::FwdParams& base, bool masked, hipStream_t stream) {
     FA_HIP(hipGetLastError());
     return FA_OK;
 }
-// Blockwise mode on the same kernel family (carried state, absolute positions): every block at D = 64 / 256.
-// FA_HD=0 / 1 keeps these on the general kernel.  (D = 128: the blocks that the tuned kernels do not take stay on
-// the general kernel; this form at D = 128, two workgroups per CU, has no register left for the carried state.)
-bool block_on_hd(int D) { return (D == 64 || D == 256) && switches().hd && switches().hd_masked; }
+// Blockwise mode on the same kernel family (carried state, absolute positions): every block at D = 64 / 256, and
+// at D = 128 the blocks that the tuned kernels do not take.  FA_HD=0 / 1 keeps these on the general kernel.
+bool block_on_hd(int D) { return (D == 64 || D == 128 || D == 256) && switches().hd && switches().hd_masked; }
 template <int D>
 int launch_hd_state(const fa::FwdParams& base, hipStream_t stream) {
     fa::FwdParams p = base;
@@ -436,11 +435,82 @@ int launch_hd_state(const fa::FwdParams& base, hipStream_t stream) {
 }
 int launch_block_other(const fa::FwdParams& p, int D, hipStream_t stream) {
     if (!block_on_hd(D)) return launch_general(p, D, stream);
-    return D == 64 ? launch_hd_state<64>(p, stream) : launch_hd_state<256>(p, stream);
+    return D == 64 ? launch_hd_state<64>(p, stream) : D == 128 ? launch_hd_state<128>(p, stream) : launch_hd_state<256>(p, stream);
 }
+
+// Key split for this kernel family (one-call entry point, no mask).  A launch is (head, 128-row block) workgroups;
+// a handful of query rows against a long sequence (the shape of a decoding step) or few heads give far fewer than
+// the chip holds (B*H = 16, Lq = 1, Lk = 65536: 16 workgroups, 0.3 TB/s).  Such launches divide every head's keys
+// into S ranges of whole tiles (the last one may be shorter), run fa_fwd_hd_state_kernel on the S * B * H virtual
+// heads, each storing its un-normalised state, and fold the ranges with fa_hd_split_merge_kernel.  Workspace per
+// virtual row: D + 2 floats, three arrays as in the D = 128 split above, from the stream's memory pool; a stream
+// under capture, or a failed allocation, gets the undivided launch.  FA_SPLIT=0 / 1: never; FA_SPLIT=k: k ranges.
+int pick_hd_split(int bh, int lq, int lk, int D, int* lk_split) {
+    const Switches& sw = switches();
+    if (sw.split == 0 || sw.split == 1 || !block_on_hd(D)) return 1;
+    const int tk = D == 64 ? fa::HdCfg<64>::kTk : D == 128 ? fa::HdCfg<128>::kTk : fa::HdCfg<256>::kTk;
+    const long items = (long)bh * ((lq + 127) / 128);
+    const long target = (long)device_cus() * (D == 256 ? 1 : 2);  // workgroups the chip holds at once
+    const int tiles = (lk + tk - 1) / tk;
+    int S = sw.split > 1 ? sw.split : (int)((target + items - 1) / items);
+    if (sw.split < 0 && (2 * items > target || lk < 2048)) return 1;
+    const int max_s = tiles / (sw.split > 1 ? 1 : 16);  // a range keeps sixteen tiles
+    if (S > max_s) S = max_s;
+    if (S > 64) S = 64;
+    if (S < 2) return 1;
+    const int per = ((tiles + S - 1) / S) * tk;  // keys per range, whole tiles
+    S = (lk + per - 1) / per;
+    if (S < 2 || (size_t)S * bh * lq * (size_t)(D + 2) * sizeof(float) > (size_t)256 << 20) return 1;
+    *lk_split = per;
+    return S;
+}
+template <int D>
+int launch_hd_split(const fa::FwdParams& base, int S, int lk_split, void* ws, hipStream_t stream) {
+    fa::FwdParams p = base;
+    const size_t rows = (size_t)base.bh * base.lq, vrows = rows * S;
+    p.bh_real = base.bh;
+    p.bh = base.bh * S;
+    p.k_splits = S;
+    p.lk_split = lk_split;
+    p.o_acc = static_cast<float*>(ws);
+    p.row_max = p.o_acc + vrows * D;
+    p.row_sum = p.row_max + vrows;
+    p.flags = fa::kFlagStoreState;
+    p.q_pos0 = p.k_pos0 = 0;
+    if (int rc = launch_hd_state<D>(p, stream)) return rc;
+    constexpr int kRowsPerBlock = 256 / (D / 4);
+    long mgrid = (long)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+    const long mmax = 8L * device_cus();
+    if (mgrid > mmax) mgrid = mmax;
+    hipLaunchKernelGGL(fa::fa_hd_split_merge_kernel<D>, dim3((unsigned)mgrid), dim3(256), 0, stream, p.o_acc, p.row_max,
+                       p.row_sum, base.o, rows, S);
+    FA_HIP(hipGetLastError());
+    return FA_OK;
+}
+// The one-call launch of this family: divided when pick_hd_split says so and the workspace can be had.
+int launch_hd_maybe_split(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream);
 int launch_hd_any(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) {
     if (D == 128) return launch_hd<128>(p, true, stream);
     return D == 64 ? launch_hd<64>(p, r == kHdMasked, stream) : launch_hd<256>(p, r == kHdMasked, stream);
+}
+int launch_hd_maybe_split(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) {
+    int lk_split = 0;
+    const int S = (p.flags == 0 && !p.q_len && !p.k_len) ? pick_hd_split(p.bh, p.lq, p.lk, D, &lk_split) : 1;
+    if (S > 1) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+        const size_t bytes = (size_t)S * p.bh * p.lq * (size_t)(D + 2) * sizeof(float);
+        void* ws = nullptr;
+        if (!capturing && hipMallocAsync(&ws, bytes, stream) == hipSuccess && ws) {
+            const int rc = D == 64    ? launch_hd_split<64>(p, S, lk_split, ws, stream)
+                           : D == 128 ? launch_hd_split<128>(p, S, lk_split, ws, stream)
+                                      : launch_hd_split<256>(p, S, lk_split, ws, stream);
+            (void)hipFreeAsync(ws, stream);
+            return rc;
+        }
+        (void)hipGetLastError();  // no stream-ordered allocator: run undivided
+    }
+    return launch_hd_any(p, D, r, stream);
 }
 
 // The masked forms of the one-wave-per-SIMD kernel: D = 128 with the causal mask (Lq == Lk) and / or lengths
@@ -617,6 +687,13 @@ int fa_split_ways(int bh, int lq, int lk) {
     if (short_self_attention_on_hd(lq, lk, 0)) return 1;
     return pick_split(bh, (lq + 255) / 256, lq, lk, persistent_grid(), kSplitMaxRows);
 }
+int fa_split_ways_general(int bh, int lq, int lk, int D, int flags) {
+    if (bh <= 0 || lq <= 0 || lk <= 0 || flags != 0 || (D != 64 && D != 128 && D != 256)) return 1;
+    if (D == fa::kHeadDim && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return fa_split_ways(bh, lq, lk);
+    if (masked_on_w64(flags, D, lq, lk) || !hd_route(flags, D, lq, lk)) return 1;
+    int lk_split = 0;
+    return pick_hd_split(bh, lq, lk, D, &lk_split);
+}
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0) {
     switch (block_route(lq, lk, D, flags, q_pos0, k_pos0)) {
         case kRouteTuned: return kKernelNames[pick_kernel(pick_waves(), lq, lk)];  // (a call that carries state)
@@ -627,7 +704,8 @@ const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q
             return masked_w64_name(p);
         }
         default:
-            if (block_on_hd(D)) return D == 64 ? "fa::fa_fwd_hd_state_kernel<64>" : "fa::fa_fwd_hd_state_kernel<256>";
+            if (block_on_hd(D))
+                return D == 64 ? "fa::fa_fwd_hd_state_kernel<64>" : D == 128 ? "fa::fa_fwd_hd_state_kernel<128>" : "fa::fa_fwd_hd_state_kernel<256>";
             return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
     }
 }
@@ -708,7 +786,7 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
     if (masked_on_w64(flags, D, Lq, Lk))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_masked(p, stream); });
     if (const HdRoute r = hd_route(flags, D, Lq, Lk))
-        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_any(p, D, r, stream); });
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_maybe_split(p, D, r, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 

@@ -220,6 +220,12 @@ const char* fa_kernel_name(int lq, int lk);
 int fa_split_ways(int bh, int lq, int lk);
 /* The same for a call of fa_forward_general (flags as there). */
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags);
+/* Into how many key ranges a call of fa_forward_general divides each head when fa_kernel_name_general names one of the
+ * fa::fa_fwd_hd_* kernels (a handful of query rows against a long sequence, or few heads: too few workgroups to fill
+ * the chip); 1: no split; otherwise fa::fa_fwd_hd_state_kernel<D> runs on the ranges, followed by
+ * fa::fa_hd_split_merge_kernel<D>.  No counterpart in the reference, whose grid is (L/64, B, H)
+ * (flash_attention_tensor_cores/wrapper.cu:74-76). */
+int fa_split_ways_general(int bh, int lq, int lk, int D, int flags);
 /* The same for a call of fa_forward_block_general. */
 const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q_pos0, int k_pos0);
 

@@ -355,7 +355,7 @@ def test_blockwise_general_hands_tuned_shapes_to_the_tuned_kernels(fa, oracle, d
     fa_env(FA_MASKED_W64=None)
     fa_env(FA_BLOCK_TUNED=None)
     name = fa.lib().fa_kernel_name_block_general
-    general, tuned = b"fa::fa_fwd_general_kernel<128>", b"fa::fa_fwd_w64_kernel"
+    general, tuned = b"fa::fa_fwd_hd_state_kernel<128>", b"fa::fa_fwd_w64_kernel"
     assert name(512, 512, 128, 1, 512, 512) == CAUSAL_TUNED     # the diagonal block
     assert name(512, 512, 128, 1, 1024, 512) == tuned           # wholly below the diagonal: no mask needed
     assert name(512, 512, 128, 1, 512, 1024) == general         # wholly above it: nothing to see
@@ -404,9 +404,9 @@ def test_blockwise_general_ragged_chunks_on_the_tuned_kernels(fa, oracle, dev, f
     name = fa.lib().fa_kernel_name_block_general
     assert name(511, 700, 128, 1, 700, 0) == b"fa::fa_fwd_w64_ragged_kernel"           # below the diagonal
     assert name(700, 700, 128, 1, 0, 0) == b"fa::fa_fwd_w64_ragged_causal_kernel"     # diagonal pair
-    assert name(600, 600, 128, 1, 0, 0) == b"fa::fa_fwd_general_kernel<128>"          # (last block a third full)
+    assert name(600, 600, 128, 1, 0, 0) == b"fa::fa_fwd_hd_state_kernel<128>"          # (last block a third full)
     assert name(600, 600, 128, 0, 0, 0) == b"fa::fa_fwd_w64_ragged_kernel"
-    assert name(50, 600, 128, 0, 0, 0) == b"fa::fa_fwd_general_kernel<128>"            # fewer than 64 query rows
+    assert name(50, 600, 128, 0, 0, 0) == b"fa::fa_fwd_hd_state_kernel<128>"            # fewer than 64 query rows
     B, H = 1, 4
     cuts = [0, 700, 1211, 1600, 1650]
     L = cuts[-1]
@@ -788,3 +788,40 @@ def test_blockwise_other_head_dims_state_values(fa, oracle, dev, D):
     assert np.abs(m - m_ref).max() <= 1e-5 * max(1.0, np.abs(m_ref).max())
     assert np.abs(l / l_ref - 1).max() <= 2e-3
     assert np.abs(o - o_ref).max() <= 2e-3 * max(1.0, np.abs(o_ref).max())
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("BH,Lq,Lk", [(4, 1, 5000), (2, 16, 8192), (3, 100, 4097), (16, 1, 20000)])
+def test_few_rows_against_many_keys_divide_the_keys(fa, oracle, dev, D, BH, Lq, Lk, fa_env):
+    """A handful of query rows against a long sequence (a decoding step): the launcher divides every head's keys into
+    ranges of whole tiles (the last one shorter), one workgroup each, and folds the partial states.  Against the
+    oracle, and against the undivided launch (FA_SPLIT=1) under the row-relative bound."""
+    import torch
+
+    fa_env(FA_HD=None, FA_SPLIT=None)
+    assert fa.lib().fa_split_ways_general(BH, Lq, Lk, D, 0) > 1
+    assert fa.lib().fa_split_ways_general(2048, Lq, Lk, D, 0) == 1  # (enough heads to fill the chip)
+    rng = np.random.default_rng(8000 + D + Lk)
+    Q = rng.standard_normal((1, BH, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((1, BH, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((1, BH, Lk, D), dtype=np.float32).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = torch.full_like(q, float("nan"))
+    fa.attention_general(q, k, v, out=o)
+    torch.cuda.synchronize()
+    st = oracle.BlockState(1, BH, Lq, D)
+    oracle.block_update(st, Q, K, V)
+    ref = oracle.block_finalize(st)
+    gate(oracle, ref, o.cpu().numpy(), f"divided keys D={D} {BH}x{Lq}x{Lk}")
+    fa_env(FA_SPLIT="1")
+    o1 = fa.attention_general(q, k, v)
+    torch.cuda.synchronize()
+    gate(oracle, ref, o1.cpu().numpy(), f"undivided D={D} {BH}x{Lq}x{Lk}")
+    a, b = o.float(), o1.float()
+    row = torch.maximum(a.abs(), b.abs()).amax(dim=-1, keepdim=True)
+    assert bool(((a - b).abs() <= 2.0 ** -9 * row + 1e-6).all())
+    # a forced count of ranges that does not divide the tiles evenly
+    fa_env(FA_SPLIT="7")
+    o7 = fa.attention_general(q, k, v)
+    torch.cuda.synchronize()
+    gate(oracle, ref, o7.cpu().numpy(), f"seven ranges D={D} {BH}x{Lq}x{Lk}")

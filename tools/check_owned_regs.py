@@ -24,7 +24,8 @@ KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causa
            "_ZN2fa23fa_fwd_w64_split_kernelENS_9FwdParamsE", "_ZN2fa16fa_fwd_hd_kernelILi256EEEvNS_9FwdParamsE",
            "_ZN2fa16fa_fwd_hd_kernelILi64EEEvNS_9FwdParamsE", "_ZN2fa23fa_fwd_hd_masked_kernelILi256EEEvNS_9FwdParamsE",
            "_ZN2fa23fa_fwd_hd_masked_kernelILi64EEEvNS_9FwdParamsE", "_ZN2fa23fa_fwd_hd_masked_kernelILi128EEEvNS_9FwdParamsE",
-           "_ZN2fa22fa_fwd_hd_state_kernelILi64EEEvNS_9FwdParamsE", "_ZN2fa22fa_fwd_hd_state_kernelILi256EEEvNS_9FwdParamsE"]
+           "_ZN2fa22fa_fwd_hd_state_kernelILi64EEEvNS_9FwdParamsE", "_ZN2fa22fa_fwd_hd_state_kernelILi128EEEvNS_9FwdParamsE",
+           "_ZN2fa22fa_fwd_hd_state_kernelILi256EEEvNS_9FwdParamsE"]
 
 
 def main():
