@@ -450,19 +450,42 @@ int pick_hd_split(int bh, int lq, int lk, int D, int* lk_split) {
     if (sw.split == 0 || sw.split == 1 || !block_on_hd(D)) return 1;
     const int tk = D == 64 ? fa::HdCfg<64>::kTk : D == 128 ? fa::HdCfg<128>::kTk : fa::HdCfg<256>::kTk;
     const long items = (long)bh * ((lq + 127) / 128);
-    const long target = (long)device_cus() * (D == 256 ? 1 : 2);  // workgroups the chip holds at once
+    const long slots = (long)device_cus() * (D == 256 ? 1 : 2);  // workgroups that fill the chip (D = 64 holds three per CU, but a third one gained nothing here)
     const int tiles = (lk + tk - 1) / tk;
-    int S = sw.split > 1 ? sw.split : (int)((target + items - 1) / items);
-    if (sw.split < 0 && (2 * items > target || lk < 2048)) return 1;
-    const int max_s = tiles / (sw.split > 1 ? 1 : 16);  // a range keeps sixteen tiles
-    if (S > max_s) S = max_s;
-    if (S > 64) S = 64;
-    if (S < 2) return 1;
-    const int per = ((tiles + S - 1) / S) * tk;  // keys per range, whole tiles
-    S = (lk + per - 1) / per;
-    if (S < 2 || (size_t)S * bh * lq * (size_t)(D + 2) * sizeof(float) > (size_t)256 << 20) return 1;
-    *lk_split = per;
-    return S;
+    auto ranges = [&](int S, int* per) {  // S ranges of whole tiles: keys per range, and how many ranges that makes
+        *per = ((tiles + S - 1) / S) * tk;
+        return (lk + *per - 1) / *per;
+    };
+    auto bytes = [&](int S) { return (double)S * bh * lq * (double)(D + 2) * sizeof(float); };
+    if (sw.split > 1) {
+        int per = 0;
+        const int S = ranges(sw.split < tiles ? sw.split : tiles, &per);
+        if (S < 2 || bytes(S) > (double)((size_t)256 << 20)) return 1;
+        *lk_split = per;
+        return S;
+    }
+    if (lk < 2048 || items >= slots) return 1;
+    // Cost model in microseconds, fitted to tools/split_mid.py and tools/decode_shapes.py: a workgroup takes about
+    // 0.8 us per tile (10 % more in the form that carries state), the second launch 10 us, and the state costs
+    // 1.3 us per MB (written as 16-byte pieces, read again by the merge).  A range keeps sixteen tiles.
+    auto rounds = [&](long n) { return (double)((n + slots - 1) / slots); };
+    const double t_tile = 0.8;
+    double best = rounds(items) * tiles * t_tile;
+    const double need = 0.9 * best;
+    int best_s = 1, best_per = 0;
+    for (int want = 2; want <= 64 && tiles / want >= 16; ++want) {
+        int per = 0;
+        const int S = ranges(want, &per);
+        if (S < 2 || bytes(S) > (double)((size_t)256 << 20)) continue;
+        const double t = rounds(items * S) * (per / tk) * t_tile * 1.1 + 10.0 + 1.3e-6 * bytes(S);
+        if (t < need && t < best) {
+            best = t;
+            best_s = S;
+            best_per = per;
+        }
+    }
+    if (best_s > 1) *lk_split = best_per;
+    return best_s;
 }
 template <int D>
 int launch_hd_split(const fa::FwdParams& base, int S, int lk_split, void* ws, hipStream_t stream) {
