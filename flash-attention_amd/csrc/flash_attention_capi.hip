@@ -450,7 +450,10 @@ int pick_hd_split(int bh, int lq, int lk, int D, int* lk_split) {
     if (sw.split == 0 || sw.split == 1 || !block_on_hd(D)) return 1;
     const int tk = D == 64 ? fa::HdCfg<64>::kTk : D == 128 ? fa::HdCfg<128>::kTk : fa::HdCfg<256>::kTk;
     const long items = (long)bh * ((lq + 127) / 128);
-    const long slots = (long)device_cus() * (D == 256 ? 1 : 2);  // workgroups that fill the chip (D = 64 holds three per CU, but a third one gained nothing here)
+    // Workgroups that fill the chip: one per CU where a workgroup computes (a kernel trace of D = 64, B*H = 8, L = 4096
+    // in two ranges: 512 workgroups took as long as 256 undivided ones), two where it mostly waits for its keys
+    // (a few query rows: D = 64 / 128 hold two and more per CU, and the second one doubled the read rate).
+    const long slots = (long)device_cus() * (D != 256 && lq <= 32 ? 2 : 1);
     const int tiles = (lk + tk - 1) / tk;
     auto ranges = [&](int S, int* per) {  // S ranges of whole tiles: keys per range, and how many ranges that makes
         *per = ((tiles + S - 1) / S) * tk;
