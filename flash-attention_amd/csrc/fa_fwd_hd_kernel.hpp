@@ -351,29 +351,30 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
     [[maybe_unused]] const int shift = STATE ? p.q_pos0 - p.k_pos0 : 0;  // keys are counted from this block's first
     [[maybe_unused]] const bool load_state = STATE && (p.flags & kFlagLoadState) != 0;
     [[maybe_unused]] const bool store_state = STATE && (p.flags & kFlagStoreState) != 0;
-    int lq_v = p.lq, lk_v = p.lk;  // this sequence's valid rows and keys
-    if constexpr (MASKED) {
-        if (causal) qb = p.q_blocks - 1 - qb;  // block qb costs qb + 1 units: the long ones first
-        if (p.q_len || p.k_len) {
-            const int batch = head / p.heads_per_batch;
-            if (p.q_len) lq_v = min(max(p.q_len[batch], 0), p.lq);
-            if (p.k_len) lk_v = min(max(p.k_len[batch], 0), p.lk);
-        }
-        if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
-    }
     // Key ranges (STATE, p.k_splits > 1; the launcher's split for shapes with few workgroups, such as a handful of
     // query rows against a long sequence): head `head` of the p.bh is range head / bh_real of real head
     // head % bh_real; it reads that head's Q rows and keys [key_first, key_first + lk_v) and stores its state under
-    // its own (virtual) head.
+    // its own (virtual) head.  (A padded sequence may end before a range begins: that range stores the empty state.)
     [[maybe_unused]] int head_q = head;
-    [[maybe_unused]] size_t key_first = 0;
+    [[maybe_unused]] int key_first = 0;
     if constexpr (STATE) {
         if (p.k_splits > 1) {
             const int range = head / p.bh_real;
             head_q = head - range * p.bh_real;
-            key_first = (size_t)range * p.lk_split;
-            lk_v = min(p.lk_split, p.lk - range * p.lk_split);
+            key_first = range * p.lk_split;
         }
+    }
+    int lq_v = p.lq, lk_v = p.lk;  // this sequence's valid rows and keys
+    if constexpr (MASKED) {
+        if (causal) qb = p.q_blocks - 1 - qb;  // block qb costs qb + 1 units: the long ones first
+        if (p.q_len || p.k_len) {
+            const int batch = (STATE ? head_q : head) / p.heads_per_batch;
+            if (p.q_len) lq_v = min(max(p.q_len[batch], 0), p.lq);
+            if (p.k_len) lk_v = min(max(p.k_len[batch], 0), p.lk);
+        }
+        if constexpr (STATE)
+            if (p.k_splits > 1) lk_v = min(max(lk_v - key_first, 0), p.lk_split);
+        if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
     }
     const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
     const bool wave_valid = q_row0 < lq_v;              // a wave past the last row computes along and stores nothing
@@ -421,8 +422,8 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         d_voff[j] = rowoff + (unsigned)((d_slot ^ ((row & HD::kVMask) << 2)) << 4);
     }
     const unsigned d_lds = ring_lds + (unsigned)(PPW * wave) * 1024u;
-    const half_t* kh = p.k + ((size_t)(STATE ? head_q : head) * p.lk + (STATE ? key_first : 0)) * D;
-    const half_t* vh = p.v + ((size_t)(STATE ? head_q : head) * p.lk + (STATE ? key_first : 0)) * D;
+    const half_t* kh = p.k + ((size_t)(STATE ? head_q : head) * p.lk + (size_t)(STATE ? key_first : 0)) * D;
+    const half_t* vh = p.v + ((size_t)(STATE ? head_q : head) * p.lk + (size_t)(STATE ? key_first : 0)) * D;
     // MASKED: the same offsets for the tile the sequence's end cuts, with every row past the last key replaced by the
     // last key's row.  (The instruction's immediate offset 1024 j is added on both sides, so it is taken off here.)
     [[maybe_unused]] unsigned d_koff_end[PPW], d_voff_end[PPW];
@@ -731,15 +732,21 @@ __global__ __launch_bounds__(HdCfg<D>::kWaves * 64, D == 128 ? 1 : HdCfg<D>::kOc
 
 // Folds the key ranges of a split launch of fa_fwd_hd_state_kernel<D> (fa_split_merge_kernel for any head dim): row i
 // of the output is  O[i] = sum_s w_s o_s[i] / sum_s w_s l_s[i],  w_s = exp(m_s[i] - max_s m_s[i])  (o_s, m_s, l_s: row
-// s * rows + i of the state arrays).  D / 4 lanes per row, four columns each.
+// s * rows + i of the state arrays).  D / 4 lanes per row, four columns each.  A row whose every range is empty
+// (a padded sequence without keys) gets 0.
 template <int D>
 __global__ __launch_bounds__(256) void fa_hd_split_merge_kernel(const float* __restrict__ o_acc, const float* __restrict__ row_max,
                                                                 const float* __restrict__ row_sum, half_t* __restrict__ o,
-                                                                size_t rows, int n_ranges) {
+                                                                size_t rows, int n_ranges, const int* __restrict__ q_len,
+                                                                int lq, int heads_per_batch) {
     constexpr int LPR = D / 4, RPB = 256 / LPR;
     const int c = threadIdx.x % LPR;
     const size_t per_pass = (size_t)gridDim.x * RPB;
     for (size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / LPR; i < rows; i += per_pass) {
+        if (q_len) {  // a padded batch: rows behind a sequence's length have no state and get no output
+            const size_t head = i / (size_t)lq;
+            if ((int)(i - head * lq) >= q_len[head / heads_per_batch]) continue;
+        }
         float m = -__builtin_inff();
         for (int s = 0; s < n_ranges; ++s) m = fmaxf(m, row_max[(size_t)s * rows + i]);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};

@@ -509,7 +509,7 @@ int launch_hd_split(const fa::FwdParams& base, int S, int lk_split, void* ws, hi
     const long mmax = 8L * device_cus();
     if (mgrid > mmax) mgrid = mmax;
     hipLaunchKernelGGL(fa::fa_hd_split_merge_kernel<D>, dim3((unsigned)mgrid), dim3(256), 0, stream, p.o_acc, p.row_max,
-                       p.row_sum, base.o, rows, S);
+                       p.row_sum, base.o, rows, S, base.q_len, base.lq, base.heads_per_batch > 0 ? base.heads_per_batch : 1);
     FA_HIP(hipGetLastError());
     return FA_OK;
 }
@@ -521,7 +521,7 @@ int launch_hd_any(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) 
 }
 int launch_hd_maybe_split(const fa::FwdParams& p, int D, HdRoute r, hipStream_t stream) {
     int lk_split = 0;
-    const int S = (p.flags == 0 && !p.q_len && !p.k_len) ? pick_hd_split(p.bh, p.lq, p.lk, D, &lk_split) : 1;
+    const int S = p.flags == 0 ? pick_hd_split(p.bh, p.lq, p.lk, D, &lk_split) : 1;  // (padded batches: by the padded lengths)
     if (S > 1) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
@@ -842,7 +842,7 @@ int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV
     p.k_len = d_k_len;
     p.heads_per_batch = H;
     if (switches().hd && switches().hd_masked)
-        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_any(p, D, kHdMasked, stream); });
+        return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_maybe_split(p, D, kHdMasked, stream); });
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 

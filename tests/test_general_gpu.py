@@ -825,3 +825,15 @@ def test_few_rows_against_many_keys_divide_the_keys(fa, oracle, dev, D, BH, Lq, 
     o7 = fa.attention_general(q, k, v)
     torch.cuda.synchronize()
     gate(oracle, ref, o7.cpu().numpy(), f"seven ranges D={D} {BH}x{Lq}x{Lk}")
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_padded_batch_of_few_rows_divides_the_keys(fa, oracle, dev, D, fa_env):
+    """A padded decoding batch (fa_forward_varlen: one to sixteen query rows per sequence, key lengths from 0 to the
+    padded 6000) takes the key split as well: ranges behind a sequence's last key hold the empty state, rows behind
+    its last query row are neither merged nor written."""
+    fa_env(FA_HD=None, FA_SPLIT=None)
+    B, H, Lq, Lk = 4, 2, 16, 6000
+    assert fa.lib().fa_split_ways_general(B * H, Lq, Lk, D, 0) > 1
+    _varlen_case(fa, oracle, dev, B, H, Lq, Lk, D, [16, 3, 0, 9], [6000, 100, 5000, 0], False, seed=9100 + D)
+    _varlen_case(fa, oracle, dev, B, H, 1, Lk, D, [1, 1, 1, 1], [1, 2049, 5999, 6000], False, seed=9200 + D)
