@@ -129,7 +129,11 @@ int fa_forward_block(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
  * Shapes the tuned kernels take (D == 128, Lq == Lk, a multiple of 64, no flags) are passed on to
  * fa_forward; other D == 128 shapes (the causal mask, lengths that are not multiples of 64, Lq != Lk)
  * run on masked forms of the same kernel where those are faster than the general one
- * (fa_kernel_name_general tells).  Asynchronous on `stream` unless elapsed_ms is non-NULL (as fa_forward). */
+ * (fa_kernel_name_general tells).  Asynchronous on `stream` unless elapsed_ms is non-NULL (as fa_forward).
+ * A launch without the mask that would leave most of the chip idle (a few query rows against a long sequence,
+ * or few heads) divides every head's keys over workgroups (fa_split_ways_general tells): its workspace,
+ * (D + 2) floats per query row and range, comes from the stream's memory pool and goes back to it in the same
+ * call, as in fa_forward; a stream under capture gets the undivided launch.  fa_forward_varlen does the same. */
 enum { FA_FLAG_CAUSAL = 1 };
 int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H,
                        int Lq, int Lk, int D, int flags, void* stream, float* elapsed_ms);
