@@ -837,3 +837,35 @@ def test_padded_batch_of_few_rows_divides_the_keys(fa, oracle, dev, D, fa_env):
     assert fa.lib().fa_split_ways_general(B * H, Lq, Lk, D, 0) > 1
     _varlen_case(fa, oracle, dev, B, H, Lq, Lk, D, [16, 3, 0, 9], [6000, 100, 5000, 0], False, seed=9100 + D)
     _varlen_case(fa, oracle, dev, B, H, 1, Lk, D, [1, 1, 1, 1], [1, 2049, 5999, 6000], False, seed=9200 + D)
+
+
+def test_divided_keys_under_stream_capture(fa, oracle, dev, fa_env):
+    """fa_forward_general on a shape that divides its keys, captured in a graph: nothing is allocated inside a capture,
+    so the launch is the undivided one there; it replays to the undivided launch's bits and within the gate."""
+    import torch
+
+    fa_env(FA_HD=None, FA_SPLIT=None)
+    BH, Lq, Lk, D = 4, 8, 6000, 128
+    assert fa.lib().fa_split_ways_general(BH, Lq, Lk, D, 0) > 1
+    rng = np.random.default_rng(31)
+    Q = rng.standard_normal((1, BH, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((1, BH, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((1, BH, Lk, D), dtype=np.float32).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    eager = fa.attention_general(q, k, v)
+    torch.cuda.synchronize()
+    o = torch.zeros_like(q)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fa.attention_general(q, k, v, out=o)  # (on the capturing stream)
+    graph.replay()
+    torch.cuda.synchronize()
+    fa_env(FA_SPLIT="1")
+    undivided = fa.attention_general(q, k, v)
+    torch.cuda.synchronize()
+    assert torch.equal(o, undivided)
+    st = oracle.BlockState(1, BH, Lq, D)
+    oracle.block_update(st, Q, K, V)
+    ref = oracle.block_finalize(st)
+    gate(oracle, ref, o.cpu().numpy(), "captured")
+    gate(oracle, ref, eager.cpu().numpy(), "eager, divided")
