@@ -337,6 +337,21 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+class JsonLine:
+    """Keeps the process's stdout for the one JSON line.  Libraries under this script write to file descriptor 1
+    themselves (RCCL prints a version banner there when the first communicator is set up), so everything else
+    that goes to descriptor 1 while the ranks run is sent to stderr."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, result):
+        sys.stdout.flush()
+        os.write(self.fd, (json.dumps(result) + "\n").encode())
+
+
 def base_result(args, world, value, wall_max):
     return {
         "metric": METRIC,
@@ -354,7 +369,7 @@ def base_result(args, world, value, wall_max):
     }
 
 
-def run_selftest(args, world, rank):
+def run_selftest(args, world, rank, line):
     """No GPU, no kernel: the launcher, the process group and the line's assembly with a stand-in step."""
     import torch
 
@@ -371,7 +386,7 @@ def run_selftest(args, world, rank):
                    "per_rank_kernel_ms": per_rank})
     ranks.close()
     if rank == 0:
-        print(json.dumps(result))
+        line.emit(result)
 
 
 def run_heads(args, fa, torch, ranks, dev):
@@ -564,8 +579,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    line = JsonLine()
     if args.selftest_cpu:
-        return run_selftest(args, world, rank)
+        return run_selftest(args, world, rank, line)
 
     import torch
 
@@ -581,7 +597,7 @@ def main():
     result = run_ring(args, fa, torch, ranks, dev) if args.ring else run_heads(args, fa, torch, ranks, dev)
     ranks.close()
     if rank == 0:
-        print(json.dumps(result))
+        line.emit(result)
 
 
 if __name__ == "__main__":

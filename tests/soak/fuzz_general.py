@@ -13,7 +13,15 @@ apart and one rounding step of the output alone would break an absolute 2e-3.
 
 D = 128 and lengths in whole 64-row tiles, the shapes that fa_forward_general and fa_forward_block_general hand to
 the tuned kernels: causal sequences in one call, and causal sequences cut into chunks (some of them ragged, which
-stay on the general kernel) with every query chunk folded over its key chunks in random order."""
+stay on the general kernel) with every query chunk folded over its key chunks in random order.
+
+    python tests/soak/fuzz_general.py --varlen
+
+Padded batches through fa_forward_varlen: random per-sequence query and key lengths (empty sequences included), NaN in
+the padding and a sentinel in the output, three kinds of shapes: self-attention up to 700 rows (with and without the
+causal mask), different query and key lengths (the causal mask counted from each sequence's start), and decoding
+batches of 1 to 16 query rows against up to 8000 keys, which the launcher divides into key ranges.  Per sequence
+the oracle runs on the truncated tensors; rows behind q_len must keep the sentinel, a sequence without keys gives 0."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,6 +33,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--tiles", action="store_true")
+ap.add_argument("--varlen", action="store_true")
 args = ap.parse_args()
 fa = ge.load_package()
 dev = torch.device("cuda:0")
@@ -40,6 +49,62 @@ def within_gate(ref, out16):
     return ok, m
 
 
+for it in range(args.iters if args.varlen else 0):
+    D = int(rng.choice([64, 128, 256]))
+    B, H = int(rng.integers(1, 7)), int(rng.integers(1, 4))
+    kind = ("self", "cross", "decode")[it % 3]
+    causal = bool(rng.integers(0, 2)) and kind != "decode"
+    if kind == "self":
+        Lq = Lk = int(rng.integers(1, 700))
+    elif kind == "cross":
+        Lq, Lk = int(rng.integers(1, 500)), int(rng.integers(1, 700))
+    else:
+        Lq, Lk = int(rng.integers(1, 17)), int(rng.integers(1000, 8000))
+    q_lens = [int(rng.integers(0, Lq + 1)) if rng.integers(0, 4) else Lq for _ in range(B)]
+    k_lens = [int(rng.integers(0, Lk + 1)) if rng.integers(0, 4) else Lk for _ in range(B)]
+    if kind == "self":
+        k_lens = list(q_lens)
+    scale = float(rng.uniform(0.3, 1.6))
+    Q = (rng.standard_normal((B, H, Lq, D), dtype=np.float32) * scale).astype(np.float16)
+    K = (rng.standard_normal((B, H, Lk, D), dtype=np.float32) * scale).astype(np.float16)
+    V = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    Qp, Kp, Vp = Q.copy(), K.copy(), V.copy()
+    for b in range(B):
+        Qp[b, :, q_lens[b]:] = np.nan
+        Kp[b, :, k_lens[b]:] = np.nan
+        Vp[b, :, k_lens[b]:] = np.nan
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Qp, Kp, Vp)]
+    o = torch.full((B, H, Lq, D), 123.0, dtype=torch.float16, device=dev)
+    fa.attention_varlen(q, k, v, torch.tensor(q_lens, dtype=torch.int32, device=dev),
+                        torch.tensor(k_lens, dtype=torch.int32, device=dev), causal=causal, out=o)
+    torch.cuda.synchronize()
+    O = o.cpu().numpy()
+    why = []
+    for b in range(B):
+        nq, nk = q_lens[b], k_lens[b]
+        if not (O[b, :, nq:] == 123.0).all():
+            why.append(f"sequence {b}: wrote behind its last query row")
+        if nq == 0:
+            continue
+        if nk == 0:
+            if not (O[b, :, :nq] == 0).all():
+                why.append(f"sequence {b}: no keys must give 0")
+            continue
+        Qs, Ks, Vs = [np.ascontiguousarray(a[b:b + 1, :, :n]) for a, n in ((Q, nq), (K, nk), (V, nk))]
+        st = oracle.BlockState(1, H, nq, D)
+        oracle.block_update(st, Qs, Ks, Vs, causal=causal, q_pos0=0, k_pos0=0)
+        ok, m = within_gate(oracle.block_finalize(st), O[b:b + 1, :, :nq])
+        if not ok:
+            why.append(f"sequence {b} (q_len {nq}, k_len {nk}): {m}")
+    if why:
+        bad += 1
+        ways = fa.lib().fa_split_ways_general(B * H, Lq, Lk, D, int(causal))
+        print(f"iter {it}: {kind} B={B} H={H} Lq={Lq} Lk={Lk} D={D} causal={causal} split={ways}: " + "; ".join(why))
+    if it % 50 == 49:
+        print(f"{it + 1} cases, {bad} failures", flush=True)
+if args.varlen:
+    print("fuzz_general --varlen:", "FAILED" if bad else "ok", f"({args.iters} cases, {bad} failures)")
+    sys.exit(1 if bad else 0)
 for it in range(args.iters if args.tiles else 0):
     B, H = int(rng.integers(1, 3)), int(rng.integers(1, 12))
     nchunk = int(rng.integers(1, 5))

@@ -225,3 +225,17 @@ def test_bench_launcher_fails_loudly_without_the_gpus():
 def test_bench_rank_rejects_a_world_that_is_not_gpus():
     r = _run_bench("--gpus", "1", "--selftest-cpu", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_stdout_carries_the_json_line_only():
+    """What a library writes to file descriptor 1 while the ranks run (RCCL prints a version banner there when the
+    first communicator is set up) goes to stderr; stdout holds the one JSON line."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; line = bench.JsonLine(); "
+            "os.write(1, b'RCCL version : banner\\n'); print('a stray print'); line.emit({'n_gpus': 1})" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"n_gpus": 1}\n'
+    assert "banner" in r.stderr and "a stray print" in r.stderr
