@@ -287,6 +287,19 @@ constexpr int slice_started(int g) {
 #endif
 }
 
+// Where the step's barrier sits.  The tiles a step reads from LDS were sent for two steps earlier; every wave
+// waits for its own pieces at the end of the step before (s_waitcnt) and the workgroup's barrier publishes
+// them.  Nothing needs that barrier before the step's first LDS read, and the first MFMAs of phase 1 take
+// operands that are already in registers: with W64_BAR_GAP = g >= 0 the barrier moves from the end of a step
+// into gap g of the next step's phase 1, behind g + 1 issued MFMAs that run while the slowest wave arrives;
+// the K fragment reads of gaps 0 .. g follow it.  The step's transfers start in gap 2 and overwrite what
+// other waves read in the step before, so g <= 1.  -1: barrier at the end of the step.
+#ifndef W64_BAR_GAP
+#define W64_BAR_GAP -1
+#endif
+static_assert(W64_BAR_GAP >= -1 && W64_BAR_GAP <= 1, "the step's transfers start in gap 2");
+__device__ __forceinline__ void step_barrier() { __builtin_amdgcn_s_barrier(); }
+
 // One phase (see the file comment), written out gap by gap: 32 MFMAs, and after each of them the
 // LDS reads and the slice of vector work that share its 32 cycles; sched_barrier(0) after every gap
 // keeps the compiler from re-ordering across gaps.  X is the sub-block on the matrix side
@@ -340,17 +353,23 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
             if constexpr (i == 0 && !REFILL) lds_wait_all();
             mfma_acc_av<XACC + 16 * (i & 3), kVbuf + 4 * i>(px[i >> 2]);
         }
+        // ---- the workgroup's barrier of the step before (W64_BAR_GAP, see there)
+        if constexpr (REFILL && gi == W64_BAR_GAP) step_barrier();
         // ---- this gap's share of the tile transfer
         if constexpr ((gi & 3) == 2) dma(std::integral_constant<int, (gi >> 2)>{});
         // ---- LDS reads: re-fill the slot the MFMA above has just taken
         if constexpr (REFILL) {
 #ifndef W64_ABLATE_KREAD
-            if constexpr (gi < 16) {
-                constexpr int ks = gi >> 1;
-                if constexpr (gi & 1)
-                    kb1[ks] = read_k_at<KB_NEXT>(w, ks, 1);
-                else
-                    kb0[ks] = read_k_at<KB_NEXT>(w, ks, 0);
+            if constexpr (gi < 16 && gi >= W64_BAR_GAP) {
+                // (the reads of the gaps in front of the barrier follow it)
+                static_for<(gi == W64_BAR_GAP ? gi : 0) + 1>([&](auto rc) {
+                    constexpr int gr = gi - decltype(rc)::value;
+                    constexpr int ks = gr >> 1;
+                    if constexpr (gr & 1)
+                        kb1[ks] = read_k_at<KB_NEXT>(w, ks, 1);
+                    else
+                        kb0[ks] = read_k_at<KB_NEXT>(w, ks, 0);
+                });
             }
 #endif
 #ifndef W64_ABLATE_VREAD
@@ -954,7 +973,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         // Everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows.  (Loads
         // complete in order among themselves; stores may overtake them, which only makes this wait longer.)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __syncthreads();
+        if constexpr (W64_BAR_GAP < 0) __syncthreads();  // (else inside the next step's phase 1)
 #endif
         if (__builtin_expect(last, 0)) {
             item = next_item;
