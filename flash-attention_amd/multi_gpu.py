@@ -26,7 +26,7 @@ nothing here mirrors a reference file; the two modes follow from the math:
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 
 def head_shard(total_heads: int, world: int, rank: int) -> Tuple[int, int]:
@@ -86,9 +86,15 @@ class _reserved_cus:
         return False
 
 
-def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_factory: Optional[Callable] = None):
+def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_factory: Optional[Callable] = None,
+                 rows_per_rank: Optional[Sequence[int]] = None):
     """Sequence-parallel forward.  q,k,v: this rank's rows, contiguous [B,H,L/P,D].
     Returns this rank's rows of O.
+
+    ``rows_per_rank`` (one entry per rank of the group, the same list on every rank) allows shards of different
+    lengths, e.g. a sequence that does not divide by the number of ranks: rank r then holds rows_per_rank[r] rows
+    of Q, K and V, and the blocks travel through buffers of the largest shard's size.  Without it every rank
+    must hold the same number of rows (nothing is exchanged to find out).
 
     ``step_fn(q, k_blk, v_blk, state, last)`` folds one K/V block into ``state`` and returns
     the output on the last step; ``state_factory(BH, Lq, D, device)`` creates the carried state.
@@ -119,9 +125,21 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
     nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
     prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
 
-    # K and V travel as one message: [2, B, H, Lk, D]
-    cur = torch.stack((k, v)).contiguous()
-    spare = torch.empty_like(cur)
+    # K and V travel as one message: [2, B, H, Lk, D], a view of the head of a flat buffer that holds the largest
+    # shard (with equal shards: the whole buffer)
+    Lk = k.shape[2]
+    if rows_per_rank is None:
+        rows = [Lk] * world
+    else:
+        rows = [int(n) for n in rows_per_rank]
+        if len(rows) != world or min(rows) < 1 or rows[rank] != Lk or Lq != Lk:
+            raise ValueError(f"rows_per_rank {rows} does not describe rank {rank} of {world} holding {Lk} rows")
+    per_row = 2 * B * H * D
+    bufs = [torch.empty(per_row * max(rows), dtype=k.dtype, device=k.device) for _ in range(2)]
+    block = lambda buf, n: buf[:2 * B * H * n * D].view(2, B, H, n, D)
+    cur = block(bufs[0], Lk)
+    cur[0].copy_(k)
+    cur[1].copy_(v)
     out = None
     with _reserved_cus(reserve):
         for s in range(world):
@@ -130,14 +148,15 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
             if not last:
                 # issued before the compute of this step, so the transfer can run beside it (the attention kernels
                 # leave RING_RESERVED_CUS units free for its kernels); the backend orders it after the previous
-                # step's kernel, which was the last reader of `spare`
-                ops = [dist.P2POp(dist.isend, cur, nxt, group), dist.P2POp(dist.irecv, spare, prv, group)]
+                # step's kernel, which was the last reader of the buffer being received into
+                nxt_blk = block(bufs[(s + 1) & 1], rows[(rank - s - 1) % world])
+                ops = [dist.P2POp(dist.isend, cur, nxt, group), dist.P2POp(dist.irecv, nxt_blk, prv, group)]
                 reqs = dist.batch_isend_irecv(ops)
             out = step_fn(q, cur[0], cur[1], state, last)
             for r in reqs:
                 r.wait()
             if not last:
-                cur, spare = spare, cur
+                cur = nxt_blk
     return out
 
 

@@ -69,6 +69,32 @@ def _ring_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _uneven_ring_worker(rank, world, port, out_dir):
+    """Shards of different lengths (a sequence that does not divide by the ranks): rows_per_rank."""
+    mg, oracle = _load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        rows = [100, 37, 192][:world]
+        B, H, L, D = 1, 2, sum(rows), 128
+        Q, K, V = normal_fp16(103, (B, H, L, D))
+        a = sum(rows[:rank])
+        sl = slice(a, a + rows[rank])
+        q, k, v = [torch.from_numpy(np.ascontiguousarray(t[:, :, sl])) for t in (Q, K, V)]
+        out = mg.ring_forward(q, k, v, step_fn=_make_step(oracle, B, H), state_factory=_CpuState, rows_per_rank=rows)
+        st = oracle.BlockState(B, H, rows[rank], D)
+        oracle.block_update(st, np.ascontiguousarray(Q[:, :, sl]), K, V, nthreads=1)
+        m = oracle.error_metrics(oracle.block_finalize(st), out.numpy())
+        ok = m["max_abs"] < 3e-4 and m["global_rel"] < 3e-4 and tuple(out.shape) == (B, H, rows[rank], D)
+        bad_list = False
+        try:
+            mg.ring_forward(q, k, v, step_fn=_make_step(oracle, B, H), state_factory=_CpuState, rows_per_rank=rows[:-1])
+        except ValueError:
+            bad_list = True
+        open(os.path.join(out_dir, f"uring_{rank}.txt"), "w").write(f"{int(ok and bad_list)} {m['max_abs']:.3e} {m['global_rel']:.3e}")
+    finally:
+        dist.destroy_process_group()
+
+
 def _shard_worker(rank, world, port, out_dir):
     mg, oracle = _load()
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -150,6 +176,14 @@ def test_ring_forward_gloo(tmp_path, world):
     mp.spawn(_ring_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         ok, *rest = open(tmp_path / f"ring_{r}.txt").read().split()
+        assert ok == "1", (r, rest)
+
+
+def test_ring_forward_uneven_shards_gloo(tmp_path):
+    world = 3
+    mp.spawn(_uneven_ring_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, *rest = open(tmp_path / f"uring_{r}.txt").read().split()
         assert ok == "1", (r, rest)
 
 
