@@ -969,6 +969,15 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         rescale_if_needed<kAccA>(need_a, mx_a, ra);
 
         // ---- end of step
+#ifdef W64_PAD_SCALAR  // (timing experiments only: extra scalar instructions where no MFMA is in flight)
+        {
+            int pad_ = t;
+#define W64_STR2(x_) #x_
+#define W64_STR(x_) W64_STR2(x_)
+            asm volatile(".rept " W64_STR(W64_PAD_SCALAR) "\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(pad_) : : "scc");
+            asm volatile("" : : "s"(pad_));
+        }
+#endif
 #ifndef W64_ABLATE_BARRIER  // (timing experiments only: wrong results)
         // Everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows.  (Loads
         // complete in order among themselves; stores may overtake them, which only makes this wait longer.)
