@@ -981,8 +981,12 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #ifndef W64_ABLATE_BARRIER  // (timing experiments only: wrong results)
         // Everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows.  (Loads
         // complete in order among themselves; stores may overtake them, which only makes this wait longer.)
+#ifndef W64_ABLATE_WAIT  // (timing experiments only: wrong results)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+#ifndef W64_ABLATE_SYNC  // (timing experiments only: wrong results)
         if constexpr (W64_BAR_GAP < 0) __syncthreads();  // (else inside the next step's phase 1)
+#endif
 #endif
         if (__builtin_expect(last, 0)) {
             item = next_item;
