@@ -895,11 +895,19 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         // ---- in the last-but-one step: the next item's Q rows
         int nhead = head, nqb = qb;
         size_t nwrow = wrow;
-        if (__builtin_expect(more_items && (t + 2 >= n_tiles), 0)) {
+#ifdef W64_Q_STAGGER
+        // the four waves send for their rows in four different steps (wave w: w steps earlier, never in the
+        // item's first step, whose write-out and state set-up still use the image): sent in one step, the
+        // 64 pieces queue on the unit's one address path
+        const int q_lead = 2 + (wave < n_tiles - 3 ? wave : n_tiles - 3);
+#else
+        constexpr int q_lead = 2;
+#endif
+        if (__builtin_expect(more_items && (t + q_lead >= n_tiles), 0)) {
             decode(next_item, nhead, nqb);
             nwrow = source_row(nhead, nqb);
 #ifndef FA_ABLATE_NO_QDMA  // (timing experiments only: wrong results)
-            if (t + 2 == n_tiles) {
+            if (t + q_lead == n_tiles) {
                 const size_t qsrc = q_row(nhead, nqb);
                 dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
                 dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
