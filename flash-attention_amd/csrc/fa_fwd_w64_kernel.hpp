@@ -223,6 +223,96 @@ __device__ __forceinline__ void acc_scale(float alpha) {
     });
 }
 
+// Building blocks of the write-out below.  volatile: it relies on the order they are written in.
+__device__ __forceinline__ f32x2 pk_mul(f32x2 x, f32x2 y) {
+    f32x2 r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(f32x2 x) {
+    unsigned w;
+    const float lo = x[0], hi = x[1];
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+    return w;
+}
+__device__ __forceinline__ unsigned pinned(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// O = acc / l of one sub-block as fp16, through its half of the staging image, straight from the registers the asm
+// owns (what store_output_rows_acc does with an accessor; same arithmetic, same bits).  This runs on the single
+// wave's critical path at every item boundary, and with one wave per SIMD nothing hides a vector instruction's
+// latency: measured (tools/micro/issue_cost.hip) an independent vector instruction issues every 4.7 cycles, one that
+// depends on its predecessor every 8.3, v_pk_mul_f32 every 6.7 (3.4 per element), v_fma_mix only every 8.7, and a
+// ds_write_b64 every 24.5 while all four waves write.  So the pieces go four at a time, in a fixed order with
+// every result used at least four instructions after it was produced:
+//   16 reads of the next four pieces | 8 v_pk_mul_f32 | 8 v_cvt_pk_f16_f32 | 4 address XORs | 4 ds_write_b64.
+// A piece is 8 bytes: columns 32 db + 8 g4 + 4 hh .. +3 of the lane's row, chunk 4 db + g4; its address is one XOR
+// away from chunk 0's (the image's swizzle only touches address bits 4-7, and the lane's slot of chunk 0 has the
+// row's low bits there).  With zero_after the accumulator is zeroed through the matrix pipe as soon as its last
+// element has been read, behind the row-wise reads and the stores instead of after them.
+#ifndef W64_LEAN_OUT
+#define W64_LEAN_OUT 1
+#endif
+template <int BASE, typename STAMP>
+__device__ __forceinline__ void store_output_rows_owned(half_t* o_rows, char* img_half, int lane, float l_run,
+                                                        bool zero_after, STAMP&& stamp) {
+    stamp(1);
+    const float l_tot = half_wave_sum(l_run);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;  // a row that has seen no key: O = 0, not 0/0
+    f32x2 inv2 = {inv, inv};
+    lane = opaque(lane);
+    const int r = lane & 31, hh = lane >> 5;
+    unsigned wr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img_half +
+                  (unsigned)(r * kRowBytes + ((r & 15) << 4) + 8 * hh);
+    asm volatile("" : "+v"(inv2), "+v"(wr));
+    stamp(2);
+    f32x2 x[2][8];
+    static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        x[0][i >> 1][i & 1] = acc_get<BASE + i>();
+    });
+    static_for<4>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        f32x2(&cur)[8] = x[g & 1];
+        if constexpr (g < 3) {
+            static_for<16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                x[(g + 1) & 1][i >> 1][i & 1] = acc_get<BASE + 16 * (g + 1) + i>();
+            });
+        }
+        static_for<8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            cur[i] = pk_mul(cur[i], inv2);
+        });
+        unsigned w[8];
+        static_for<8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            w[i] = cvt_pk_f16(cur[i]);
+        });
+        unsigned ad[4];
+        static_for<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            ad[i] = pinned(wr ^ (unsigned)((4 * g + i) << 4));
+        });
+        static_for<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const u32x2 both = {w[2 * i], w[2 * i + 1]};
+            *(__attribute__((address_space(3))) u32x2*)(size_t)ad[i] = both;
+        });
+    });
+    if (zero_after) acc_zero<BASE>();
+    // (written as 8-byte pieces, read back as u32x4: accesses of different types, which the compiler may reorder)
+    asm volatile("" ::: "memory");
+    stamp(3);
+    store_staged_rows(o_rows, img_half, lane, 0);
+    stamp(4);
+}
+template <int BASE>
+__device__ __forceinline__ void store_output_rows_owned(half_t* o_rows, char* img_half, int lane, float l_run,
+                                                        bool zero_after) {
+    store_output_rows_owned<BASE>(o_rows, img_half, lane, l_run, zero_after, [](int) {});
+}
 // The rescale decision of fa::softmax_tile, for scores whose scaled row max mx is already known.
 // Runs between two phases: no MFMA is in flight on the accumulator.
 // need: some row's max runs ahead of its reference by more than the slack.
@@ -322,11 +412,13 @@ __device__ __forceinline__ void step_barrier() { __builtin_amdgcn_s_barrier(); }
 //            gaps 2, 6, 10, ... 30
 // Gaps 0-15 are S_X (k-step g/2, key block g&1), gaps 16-31 O_X (V fragment g-16).  The row max of
 // S_X starts in gap 19, three MFMAs after the last one that wrote S_X.
-template <bool REFILL, int XACC, int QBASE, int KB_NEXT, int VB_NEXT, typename DMA>
+//   xdma(g)  a caller's own transfers in gap g (g is an integral_constant; called in every gap): the next item's Q
+//            rows trickling in beside the tiles (QSTREAM below); nothing otherwise
+template <bool REFILL, int XACC, int QBASE, int KB_NEXT, int VB_NEXT, typename DMA, typename XDMA>
 __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (&kb1)[8], f32x16& sx0, f32x16& sx1,
                                             const half8 (&px)[4], float& mx_x, float m_x, lane_mask_t& need_x,
                                             f32x16& sy0, f32x16& sy1, float m_y, float& l_y, half8 (&py)[4], float c,
-                                            DMA&& dma) {
+                                            DMA&& dma, XDMA&& xdma) {
     launder(w);
     const float nm = -m_y;
     float sum = 0.0f;
@@ -357,6 +449,7 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
         if constexpr (REFILL && gi == W64_BAR_GAP) step_barrier();
         // ---- this gap's share of the tile transfer
         if constexpr ((gi & 3) == 2) dma(std::integral_constant<int, (gi >> 2)>{});
+        xdma(std::integral_constant<int, gi>{});
         // ---- LDS reads: re-fill the slot the MFMA above has just taken
         if constexpr (REFILL) {
 #ifndef W64_ABLATE_KREAD
@@ -455,6 +548,15 @@ __device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (
 #undef W64_Y
 }
 
+template <bool REFILL, int XACC, int QBASE, int KB_NEXT, int VB_NEXT, typename DMA>
+__device__ __forceinline__ void fused_phase(W64Geom& w, half8 (&kb0)[8], half8 (&kb1)[8], f32x16& sx0, f32x16& sx1,
+                                            const half8 (&px)[4], float& mx_x, float m_x, lane_mask_t& need_x,
+                                            f32x16& sy0, f32x16& sy1, float m_y, float& l_y, half8 (&py)[4], float c,
+                                            DMA&& dma) {
+    fused_phase<REFILL, XACC, QBASE, KB_NEXT, VB_NEXT>(w, kb0, kb1, sx0, sx1, px, mx_x, m_x, need_x, sy0, sy1, m_y, l_y,
+                                                       py, c, dma, [](auto) {});
+}
+
 // O_X += V^T.P_X^T alone (the stream's last half tile), from the fragments already in registers.
 template <int XACC>
 __device__ __forceinline__ void pv_only(const half8 (&px)[4]) {
@@ -494,6 +596,20 @@ __device__ __forceinline__ void first_scores(W64Geom& w, half8 (&kb0)[8], half8 
     }
     mx_x = half_wave_max(fmaxf(a0, a1)) * c;
 }
+
+#ifdef W64_FINE_STAMPS
+// Diagnostic build (tools/stamps_w64.py): the low 32 bits of the shader clock, kept in lane `idx` of one of two
+// vector registers per wave (no memory traffic inside the loop) and dumped at the kernel's end.  m0 is the lane
+// select: stamps are taken between phases only, where no transfer relies on it.
+__device__ __forceinline__ void fine_stamp(unsigned& sv0, unsigned& sv1, int idx) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned lo = (unsigned)t;
+    if (idx < 64)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(sv0) : "s"(lo), "s"(idx) : "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(sv1) : "s"(lo), "s"(idx - 64) : "m0");
+}
+#endif
 
 // Causal item order.  With the mask of attention_cpu (testing.cu:74-77: key <= query row) query block qb
 // needs only the tiles up to its diagonal, 4 (qb + 1) of them, so items differ in length.  Items are
@@ -556,9 +672,22 @@ __device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int thr, int
 //     un-normalised state to row vh * lq + i of (o_acc, row_max, row_sum) (the launcher sets kFlagStoreState and
 //     points them at a workspace; fa_split_merge_kernel folds the ranges).  For launches with fewer items than
 //     compute units.
-template <bool CAUSAL, bool RAGGED, bool SPLIT = false>
+//   QSTREAM (whole tiles, no mask, items of 7 tiles or more) brings the next item's Q rows in four pieces per wave
+//     and step during the item's steps 1 to 4, one piece per MFMA gap beside the tile transfers, instead of
+//     sixteen at once in the last step but one: a workgroup's 64 pieces of 1 KiB take the unit's address path
+//     about a thousand cycles, and sent in one go every wave sits out the queue (measured with cycle stamps at
+//     L = 512: that step ran 2 000 - 2 900 cycles longer than its neighbours).  A phase must stay one basic
+//     block, so the four extra transfers are issued in EVERY step; outside steps 1 to 4 they repeat four of
+//     the step's own K pieces (same source, same destination).  The per-lane offsets of a K piece fit the Q
+//     rows as well (same rows-of-four, same swizzle; the wave's row block moves into the scalar base).
+//     Measured (bit-identical results): the step that used to send the rows runs like its neighbours, but the
+//     four steps that carry them run 150 - 250 cycles longer and every other step 80: +1 % at L = 448 and 512,
+//     nothing at 640 - 1024, -1 ... 2 % from 1280 on.  Not instantiated in the library; -DW64_QSTREAM_DEFAULT=true
+//     builds the plain kernel in this form (tools/build_w64_only.sh).
+template <bool CAUSAL, bool RAGGED, bool SPLIT = false, bool QSTREAM = false>
 __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     static_assert(!SPLIT || (!CAUSAL && !RAGGED), "the key split is built for whole tiles without a mask");
+    static_assert(!QSTREAM || (!CAUSAL && !RAGGED && !SPLIT), "Q streaming is built for the plain form");
     constexpr bool MASKED = CAUSAL || RAGGED;
     constexpr int NWAVES = 4;
     constexpr int QB = 256;                        // query rows per item
@@ -634,7 +763,25 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     struct Cursor {
         int item, tile, nt;  // nt: tiles of the cursor's item
         size_t off;
+        int head, qb;  // of the cursor's item
     };
+    // Items advance by `stride`, so (head, block) of the next item follow from the current ones without a
+    // division (an emulated one costs about 220 cycles at every item boundary).  With the XCD-aware numbering
+    // (decode_item: item = 8 j + x, head = 8 (j / q_blocks) + x, block = j % q_blocks) j advances by stride / 8 and
+    // x stays, provided stride is a multiple of 8; with the plain numbering item itself plays j's part.  Either way
+    //   block += inc_qb, head += inc_head, and on block >= q_blocks: block -= q_blocks, head += inc_wrap.
+    // inc_wrap = 0 marks the one case this does not cover (XCD-aware numbering on a grid that is no multiple of 8);
+    // the causal order has its own numbering and keeps the division.
+    [[maybe_unused]] int inc_qb = 0, inc_head = 0, inc_wrap = 0;
+    if constexpr (!CAUSAL) {
+        const bool xcd = (p.bh & 7) == 0;
+        if (!xcd || (stride & 7) == 0) {
+            const int u = xcd ? stride >> 3 : stride;
+            inc_wrap = xcd ? 8 : 1;
+            inc_head = (u / p.q_blocks) * inc_wrap;
+            inc_qb = u % p.q_blocks;
+        }
+    }
 #define W64_ADVANCE(cur_)                                                                      \
     do {                                                                                       \
         if (__builtin_expect((cur_).tile + 1 < (CAUSAL ? (cur_).nt : n_tiles_all), 1)) {       \
@@ -644,10 +791,18 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         } else if ((cur_).item + stride < n_items) {                                           \
             (cur_).item += stride;                                                             \
             (cur_).tile = 0;                                                                   \
-            int h_, q_;                                                                        \
-            decode((cur_).item, h_, q_);                                                       \
-            (cur_).nt = item_tiles(q_);                                                        \
-            (cur_).off = kv_base(h_);                                                          \
+            if (!CAUSAL && inc_wrap != 0) {                                                    \
+                (cur_).qb += inc_qb;                                                           \
+                (cur_).head += inc_head;                                                       \
+                if ((cur_).qb >= p.q_blocks) {                                                 \
+                    (cur_).qb -= p.q_blocks;                                                   \
+                    (cur_).head += inc_wrap;                                                   \
+                }                                                                              \
+            } else {                                                                           \
+                decode((cur_).item, (cur_).head, (cur_).qb);                                   \
+            }                                                                                  \
+            (cur_).nt = item_tiles((cur_).qb);                                                 \
+            (cur_).off = kv_base((cur_).head);                                                 \
         }                                                                                      \
     } while (0)
 #define W64_DMA_K(slot_)                                                                       \
@@ -699,7 +854,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // rows at the head of the wave's 64 that another wave owns (RAGGED, last rows of the sequence)
     [[maybe_unused]] auto rows_skipped = [&](int blk) -> int { return blk * QB + wave * 64 - row_pos(blk); };
     size_t wrow = source_row(head, qb);  // this wave's first query row (where its output or state goes)
-    Cursor kc = {item, 0, n_tiles, kv_base(head)};
+    Cursor kc = {item, 0, n_tiles, kv_base(head), head, qb};
     // Causal mask: `lim` is the position of the wave's first query row (in keys); a tile whose last key
     // lies beyond a sub-block's first row takes the mask (mask_scores, between the phases).
     [[maybe_unused]] int lim = row_pos(qb);
@@ -809,10 +964,11 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     [[maybe_unused]] int skip_b = 0;  // rows_skipped() of the item out_b names
 
 #ifdef FA_ABLATE_NO_WRITEOUT  // (timing experiments only: wrong results)
-#define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_) do { } while (0)
+#define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_, zero_, zeroed_) do { zeroed_ = false; } while (0)
 #else
-#define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_)                                     \
+#define W64_WRITE_OUT(base_, st_, row_, off_, img_, skip_, zero_, zeroed_)                     \
     do {                                                                                       \
+        zeroed_ = false;                                                                       \
         if ((row_) != kNoRows) {                                                               \
             const size_t r_ = (row_) + (off_);                                                 \
             if constexpr (RAGGED) {                                                            \
@@ -829,6 +985,11 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
                 if (p.flags & kFlagStoreState)                                                 \
                     store_state_rows(p, r_, (img_), lane, OwnedAcc<base_>{}, (st_).m_run, (st_).m_true, \
                                      (st_).l_run, 0);                                          \
+                else if (W64_LEAN_OUT) {                                                       \
+                    store_output_rows_owned<base_>(p.o + r_ * kHeadDim, (img_), lane, (st_).l_run, (zero_), \
+                                                   wo_stamp);                                  \
+                    zeroed_ = (zero_);                                                         \
+                }                                                                              \
                 else                                                                           \
                     store_output_rows_acc(p.o + r_ * kHeadDim, (img_), lane, OwnedAcc<base_>{}, \
                                           (st_).l_run, 0);                                     \
@@ -839,7 +1000,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // Start of an item for one sub-block, given the scaled row max mx_ of its first tile.  A fresh item
     // takes that max as its reference at once (nothing to rescale: O = 0, l = 0); a continued one
     // (blockwise mode) loads its state and decides as for any other tile.  Sets need_ accordingly.
-#define W64_INIT(base_, st_, row_, mx_, need_, img_)                                           \
+#define W64_INIT(base_, st_, row_, mx_, need_, img_, zeroed_)                                  \
     do {                                                                                       \
         if (p.flags & kFlagLoadState) {                                                        \
             if constexpr (RAGGED) {                                                            \
@@ -853,7 +1014,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             }                                                                                  \
             need_ = rescale_needed(mx_, (st_).m_run);                                          \
         } else {                                                                               \
-            acc_zero<base_>();                                                                 \
+            if (!(zeroed_)) acc_zero<base_>();                                                 \
             (st_).m_run = (st_).m_true = (mx_);                                                \
             (st_).l_run = 0.0f;                                                                \
             need_ = 0;                                                                         \
@@ -866,8 +1027,56 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // have two steps to land: the wait at the end of a step leaves the step's own eight pieces in
     // flight.  Returns true at the end of the stream.
     int t = 0;
+    // (head, block) of item `it` = the item after (hd, blk) in this workgroup's sequence
+    [[maybe_unused]] auto next_of = [&](int hd, int blk, int it, int& nh, int& nb) {
+        if (!CAUSAL && inc_wrap != 0) {
+            nb = blk + inc_qb;
+            nh = hd + inc_head;
+            if (nb >= p.q_blocks) {
+                nb -= p.q_blocks;
+                nh += inc_wrap;
+            }
+        } else {
+            decode(it, nh, nb);
+        }
+    };
+    [[maybe_unused]] const unsigned img_lds =
+        __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)img);
+    int nhead = head, nqb = qb;  // the next item, known from its last-but-one step on
+    size_t nwrow = wrow;
+#ifdef W64_FINE_STAMPS
+    // seven stamps per step (those of W64_FINE_STAMPS_MASK: a stamp costs about a hundred cycles and drains the
+    // wave's LDS reads) for 18 steps, from the workgroup's W64_FINE_STAMPS-th step on
+#ifndef W64_FINE_STAMPS_MASK
+#define W64_FINE_STAMPS_MASK 0x7f
+#endif
+    unsigned sv0 = 0, sv1 = 0;
+    int gs = 0;  // steps this workgroup has run
+    auto dump_stamps = [&]() {
+        if (p.stamps) {
+            unsigned* o = reinterpret_cast<unsigned*>(p.stamps + 4 * 256) + ((size_t)blockIdx.x * 4 + wave) * 128;
+            o[lane] = sv0;
+            o[64 + lane] = sv1;
+        }
+    };
+#define W64_STAMP(k_)                                                                          \
+    do {                                                                                       \
+        if ((W64_FINE_STAMPS_MASK >> (k_) & 1) && gs >= W64_FINE_STAMPS && gs < W64_FINE_STAMPS + 18) \
+            fine_stamp(sv0, sv1, 7 * (gs - W64_FINE_STAMPS) + (k_));                           \
+    } while (0)
+#else
+#define W64_STAMP(k_) do { } while (0)
+#endif
+#if defined(W64_FINE_STAMPS) && defined(W64_STAMP_WO)  // (points 1-4 inside sub-block A's write-out instead)
+    auto wo_stamp = [&](int k_) {
+        if (t + 1 == n_tiles) W64_STAMP(k_);
+    };
+#else
+    auto wo_stamp = [](int) {};
+#endif
     auto step = [&](auto sc) -> bool {
         constexpr int SC = decltype(sc)::value, SC1 = (SC + 1) % kSlots, SC2 = (SC + 2) % kSlots;
+        W64_STAMP(0);
         const bool first = (t == 0), last = (t + 1 == n_tiles);
         const int next_item = item + stride;
         const bool more_items = next_item < n_items;
@@ -892,26 +1101,40 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #endif
         };
         auto dma_none = [&](auto) {};
-        // ---- in the last-but-one step: the next item's Q rows
-        int nhead = head, nqb = qb;
-        size_t nwrow = wrow;
-#ifdef W64_Q_STAGGER
-        // the four waves send for their rows in four different steps (wave w: w steps earlier, never in the
-        // item's first step, whose write-out and state set-up still use the image): sent in one step, the
-        // 64 pieces queue on the unit's one address path
-        const int q_lead = 2 + (wave < n_tiles - 3 ? wave : n_tiles - 3);
-#else
-        constexpr int q_lead = 2;
-#endif
-        if (__builtin_expect(more_items && (t + q_lead >= n_tiles), 0)) {
-            decode(next_item, nhead, nqb);
+        // ---- QSTREAM: this step's four extra pieces (gaps 0, 1, 15, 16: one per gap, the LDS base set in the first
+        //      of each pair; the tile transfers set their own bases in gaps 2 and 18)
+        [[maybe_unused]] unsigned x_base = k_dst;
+        [[maybe_unused]] const half_t* x_src = k_src;
+        if constexpr (QSTREAM) {
+            if (__builtin_expect(t == 1 && more_items, 0)) {
+                next_of(head, qb, next_item, nhead, nqb);
+                nwrow = source_row(nhead, nqb);
+            }
+            if (more_items && t >= 1 && t <= 4) {
+                // group t - 1 of the next item's 64 rows: 16 rows, 4 KiB on both sides
+                x_base = img_lds + 4096u * (unsigned)(t - 1);
+                x_src = p.q + (q_row(nhead, nqb) + (size_t)(16 * (t - 1))) * kHeadDim - (size_t)wave * 2048;
+            }
+        }
+        auto xdma_step = [&](auto gc) {
+            constexpr int gx = decltype(gc)::value;
+            if constexpr (QSTREAM && (gx == 0 || gx == 1 || gx == 15 || gx == 16)) {
+                constexpr int e = gx < 2 ? gx : gx - 13;
+                if constexpr (gx == 0 || gx == 15) dma_set_base(x_base);
+                dma_piece_at<1024 * e>(x_src, d_koff[e]);
+            }
+        };
+        // ---- in the last-but-one step: the next item's Q rows.  The load cursor, three tiles ahead, is on the
+        //      next item's third tile by then: that item's head and block are the cursor's (kept for the last step,
+        //      by which the cursor may have moved on to the item after).
+        if (!QSTREAM && __builtin_expect(more_items && (t + 2 == n_tiles), 0)) {
+            nhead = kc.head;
+            nqb = kc.qb;
             nwrow = source_row(nhead, nqb);
 #ifndef FA_ABLATE_NO_QDMA  // (timing experiments only: wrong results)
-            if (t + q_lead == n_tiles) {
-                const size_t qsrc = q_row(nhead, nqb);
-                dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
-                dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
-            }
+            const size_t qsrc = q_row(nhead, nqb);
+            dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
+            dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
 #endif
         }
 
@@ -919,8 +1142,14 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         // In an item's last step A's next Q fragments are requested here: Q_A is idle while B is on the
         // matrix side, and the rows arrived with the previous step's end-of-step wait.
         if (__builtin_expect(last && more_items, 0)) q_install_issue<kQregA>(img, lane);
+#ifndef W64_STAMP_WO
+        W64_STAMP(1);
+#endif
         fused_phase<true, kAccB, kQregB, SC1 * kTileBytes, SC * kTileBytes>(
-            w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step);
+            w, kb0, kb1, sb0, sb1, pb, mx_b, rb.m_run, need_b, sa0, sa1, ra.m_run, ra.l_run, pa, c, dma_step, xdma_step);
+#ifndef W64_STAMP_WO
+        W64_STAMP(2);
+#endif
         if constexpr (MASKED) {
             // S_B(t): rows lim + 32 .. lim + 63 against tile t
             if (__builtin_expect(needs_mask(t, lim + 32), 0)) {
@@ -930,10 +1159,11 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         }
         if (__builtin_expect(first, 0)) {
             // O_B of the previous item is complete: write it out, then start the new item's state
-            W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b);
+            bool zeroed;
+            W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b, true, zeroed);
             out_b = owns_rows(qb) ? wrow : kNoRows;
             if constexpr (RAGGED) skip_b = rows_skipped(qb);
-            W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b, img + 32 * kRowBytes);
+            W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b, img + 32 * kRowBytes, zeroed);
         }
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
 
@@ -944,8 +1174,14 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             lds_wait_all();
             q_install_issue<kQregB>(img + 32 * kRowBytes, lane);
         }
+#ifndef W64_STAMP_WO
+        W64_STAMP(3);
+#endif
         fused_phase<false, kAccA, kQregA, 0, 0>(
             w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
+#ifndef W64_STAMP_WO
+        W64_STAMP(4);
+#endif
         if constexpr (MASKED) {
             // S_A(t+1), or in an item's last step S_A(0) of the next item: rows lim .. lim + 31
             const int tile_a = last ? 0 : t + 1, pos_a = last ? row_pos(nqb) : lim;
@@ -955,12 +1191,16 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             }
         }
         if (__builtin_expect(last, 0)) {
-            W64_WRITE_OUT(kAccA, ra, (owns_rows(qb) ? wrow : kNoRows), 0, img, rows_skipped(qb));
+            bool zeroed;
+            W64_WRITE_OUT(kAccA, ra, (owns_rows(qb) ? wrow : kNoRows), 0, img, rows_skipped(qb), more_items, zeroed);
             if (!more_items) {
                 // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
                 pv_only<kAccB>(pb);
-                W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b);
+                W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b, false, zeroed);
                 wait_all_vmem();  // the last step's (redundant) transfers must not outlive the workgroup's LDS
+#ifdef W64_FINE_STAMPS
+                dump_stamps();
+#endif
 #ifdef FA_STAMPS
                 if (p.stamps && tid == 0) {
                     unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
@@ -972,11 +1212,12 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #endif
                 return true;
             }
-            W64_INIT(kAccA, ra, nwrow, mx_a, need_a, img);
+            W64_INIT(kAccA, ra, nwrow, mx_a, need_a, img, zeroed);
         }
         rescale_if_needed<kAccA>(need_a, mx_a, ra);
 
         // ---- end of step
+        W64_STAMP(5);
 #ifdef W64_PAD_SCALAR  // (timing experiments only: extra scalar instructions where no MFMA is in flight)
         {
             int pad_ = t;
@@ -990,11 +1231,18 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         // Everything older than this step's eight pieces has landed: K(t+2), V(t+1), any Q rows.  (Loads
         // complete in order among themselves; stores may overtake them, which only makes this wait longer.)
 #ifndef W64_ABLATE_WAIT  // (timing experiments only: wrong results)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (QSTREAM)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (twelve pieces per step)
+        else
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
+        W64_STAMP(6);
 #ifndef W64_ABLATE_SYNC  // (timing experiments only: wrong results)
         if constexpr (W64_BAR_GAP < 0) __syncthreads();  // (else inside the next step's phase 1)
 #endif
+#endif
+#ifdef W64_FINE_STAMPS
+        ++gs;
 #endif
         if (__builtin_expect(last, 0)) {
             item = next_item;
@@ -1015,7 +1263,14 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) { fa_fwd_w64_body<false, false>(p); }
+#ifndef W64_QSTREAM_DEFAULT  // (experiment builds: the plain kernel in the Q-streaming form, see QSTREAM)
+#define W64_QSTREAM_DEFAULT false
+#endif
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
+    fa_fwd_w64_body<false, false, false, W64_QSTREAM_DEFAULT>(p);
+}
+
+#ifndef FA_W64_ONLY  // (experiment builds of the default kernel alone, tools/build_w64_only.sh, leave the other forms out)
 // The same with the causal mask, lengths in whole tiles.
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_causal_kernel(const FwdParams p) { fa_fwd_w64_body<true, false>(p); }
 // The same for lengths that are not whole tiles, without and with the causal mask.
@@ -1027,6 +1282,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_causal_kernel(const 
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_split_kernel(const FwdParams p) {
     fa_fwd_w64_body<false, false, true>(p);
 }
+#endif
 
 // Folds the key ranges of fa_fwd_w64_split_kernel: row i of the output is
 //   O[i] = sum_s w_s o_s[i] / sum_s w_s l_s[i],   w_s = exp(m_s[i] - max_s m_s[i]),
@@ -1056,6 +1312,7 @@ __global__ __launch_bounds__(256) void fa_split_merge_kernel(const float* __rest
     }
 }
 
+#undef W64_STAMP
 #undef W64_ADVANCE
 #undef W64_DMA_K
 #undef W64_DMA_V

@@ -10,6 +10,9 @@ blocks, anywhere in the function (a kernel with early exits has several s_endpgm
 function's end label).
 
     python tools/check_owned_regs.py [extra hipcc flags...]
+
+Environment (experiment builds): FA_AUDIT_SRC = another source file, FA_AUDIT_KERNELS = comma-separated mangled
+names to audit instead of the library's list, FA_AUDIT_KEEP = where to keep the assembly.
 """
 import os
 import re
@@ -29,13 +32,17 @@ KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causa
 
 
 def main():
+    src = os.environ.get("FA_AUDIT_SRC", SRC)
+    kernels = os.environ["FA_AUDIT_KERNELS"].split(",") if os.environ.get("FA_AUDIT_KERNELS") else KERNELS
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "capi.s")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-honor-nans", "-S",
-               "--cuda-device-only", "-o", out, SRC] + sys.argv[1:]
+               "--cuda-device-only", "-o", out, src] + sys.argv[1:]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
-    for kernel in KERNELS:
+        if os.environ.get("FA_AUDIT_KEEP"):
+            open(os.environ["FA_AUDIT_KEEP"], "w").write(text)
+    for kernel in kernels:
         audit(text, kernel)
     print("check_owned_regs: ok (no spills, no scratch, no compiler use of accumulator registers)")
 

@@ -1,0 +1,59 @@
+// Experiment build of the default kernel alone: fa_forward with the library's signature, launching
+// fa::fa_fwd_w64_kernel on whole-tile shapes and nothing else.  Compiles in a fraction of the library's time;
+// tools/ab.py, tools/clock.py and tools/stamps_w64.py load it beside the product library.
+//   tools/build_w64_only.sh NAME [-DFLAG ...]  ->  build_ab/NAME.so, build_ab/NAME.s
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../flash-attention_amd/csrc/fa_fwd_kernel.hpp"
+#include "../../flash-attention_amd/csrc/fa_fwd_ring_kernel.hpp"
+#include "../../flash-attention_amd/csrc/fa_fwd_w64_kernel.hpp"
+
+namespace {
+unsigned long long* g_stamps = nullptr;
+int g_grid_max = 256;
+}
+
+extern "C" {
+void fa_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
+void fa_debug_reload_env(void) {}
+void fa_debug_set_grid(int g) { g_grid_max = g; }
+
+int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L, int D,
+               int tile, void* stream, float* elapsed_ms) {
+    if (D != 128 || tile != 64 || L % 64 || L < 320 || elapsed_ms && false) return 1;
+    fa::FwdParams p = {};
+    p.q = reinterpret_cast<const fa::half_t*>(dQ);
+    p.k = reinterpret_cast<const fa::half_t*>(dK);
+    p.v = reinterpret_cast<const fa::half_t*>(dV);
+    p.o = reinterpret_cast<fa::half_t*>(dO);
+    p.bh = B * H;
+    p.lq = p.lk = L;
+    p.q_blocks = (L + 255) / 256;
+    p.scale_log2e = 1.44269504088896340736f / sqrtf((float)D);
+    p.stamps = g_stamps;
+    const long items = (long)p.bh * p.q_blocks;
+    long grid = items;
+    if (items > g_grid_max) {
+        const long rounds = (items + g_grid_max - 1) / g_grid_max;
+        grid = ((items + rounds - 1) / rounds + 7) & ~7L;
+        if (grid > g_grid_max) grid = g_grid_max;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (elapsed_ms) {
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, (hipStream_t)stream);
+    }
+    hipLaunchKernelGGL(fa::fa_fwd_w64_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (hipGetLastError() != hipSuccess) return 2;
+    if (elapsed_ms) {
+        hipEventRecord(e1, (hipStream_t)stream);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(elapsed_ms, e0, e1);
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    }
+    return 0;
+}
+}
