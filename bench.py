@@ -16,7 +16,9 @@ non-zero if the ranks cannot be started or do not finish.
 Modes.
   (default)         every rank runs the same README shape on its own GPU ("weak"): the path shards over
                     independent (batch, head) pairs, so there is no data-path collective; the only
-                    collectives are the barrier and the max-over-ranks of the timing.
+                    collectives are the barrier and the max-over-ranks of the timing.  With more than one
+                    rank the line also carries `strong_c4`: B=1, H=16, L=16384 with its heads split over
+                    the ranks, timed right after (--no-strong-c4 skips it).
   --scaling strong  the B*H heads of ONE shape are split across the ranks (with --seq-len 16384: B=1, H=16
                     over 1/2/4/8 GPUs); still no data-path collective.
   --ring            sequence-parallel ring (default --seq-len 131072, B=1, H=16): rank r owns L/N rows of
@@ -31,6 +33,10 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   normal_data_tflops, reference_protocol_tflops
                 the timed shape on N(0,1) inputs (compare_impls.py:84-87), and with the reference driver's
                 own protocol (warm-up 3, five launches, one event pair each, no preheat; :148-215)
+  clock_ghz_effective, clock_ghz_effective_normal_data
+                the shader clock under the kernel's own load on either data set (in-kernel s_memtime /
+                s_memrealtime stamps of the library's diagnostic twin): the two data sets run the same
+                cycles at different clocks
 """
 from __future__ import annotations
 
@@ -75,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip normal_data_tflops / reference_protocol_tflops")
+    ap.add_argument("--no-strong-c4", action="store_true",
+                    help="multi-rank default mode: skip the strong-scaling point (B=1, H=16, L=16384 split by heads)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds the ranks may take")
     ap.add_argument("--selftest-cpu", action="store_true",
@@ -103,14 +111,38 @@ def free_port():
     return port
 
 
+def count_gpus(sysfs_root="/sys/class/kfd/kfd/topology/nodes", env=None):
+    """GPUs of this node without loading a GPU runtime: the kernel driver's topology lists every agent as a node,
+    and a GPU is a node with SIMDs (`simd_count` > 0 in its `properties`; CPUs have 0).  A visibility list in the
+    environment (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES) caps the count the way the
+    runtime would."""
+    env = os.environ if env is None else env
+    n = 0
+    try:
+        nodes = sorted(os.listdir(sysfs_root))
+    except OSError:
+        nodes = []
+    for node in nodes:
+        try:
+            with open(os.path.join(sysfs_root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue  # (a node this user may not read is not a GPU this user can run on)
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if env.get(var, "").strip():
+            n = min(n, len([x for x in env[var].split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(args, argv):
-    """Start args.gpus rank processes of this script and relay rank 0's JSON line.  Nothing here initialises a
-    GPU: counting devices does not, and the ranks are fresh children (never a re-exec of this process)."""
+    """Start args.gpus rank processes of this script and relay rank 0's JSON line.  Nothing here loads a GPU
+    runtime (the GPUs are counted from sysfs, torch is not imported), and the ranks are fresh children (never a
+    re-exec of this process)."""
     n = args.gpus
     if not args.selftest_cpu:
-        import torch
-
-        have = torch.cuda.device_count()
+        have = count_gpus()
         if have < n:
             print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
             return 2
@@ -214,13 +246,16 @@ def roofline(fa, L, bh_local, ms_launch):
     gbps = algo_bytes / sec / 1e9
     hbm_bound = algo_bytes / (PEAK_HBM_GBPS * 1e9) > flops / (PEAK_TFLOPS * 1e12)
     ways = fa.lib().fa_split_ways(bh_local, L, L)
+    traffic, src = measured_traffic(L) if bh_local * L == 16384 * H_DEFAULT else (None, None)
     return {
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": gbps if hbm_bound else tflops,
         "peak": PEAK_HBM_GBPS if hbm_bound else PEAK_TFLOPS,
         "unit": "GB/s" if hbm_bound else "TFLOP/s",
         "frac": (gbps / PEAK_HBM_GBPS) if hbm_bound else (tflops / PEAK_TFLOPS),
-        "traffic": measured_traffic(L) if bh_local * L == 16384 * H_DEFAULT else None,
+        "traffic": traffic,
+        "traffic_source": (f"{src} (committed rocprofv3 summary of this shape: separate FETCH_SIZE and WRITE_SIZE "
+                           "passes, not measured in this run)") if traffic is not None else None,
         "kernel": fa.lib().fa_kernel_name(L, L).decode() if ways <= 1 else "fa::fa_fwd_w64_split_kernel",
         "key_split_ways": ways,
         "kernel_ms": ms_launch,
@@ -282,16 +317,59 @@ def cpu_baseline(B, H, L, target_s):
 def measured_traffic(L):
     """HBM bytes per launch of this shape from the newest committed rocprofv3 counter summary
     (profiles/*_L<L>.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
-    WRITE_SIZE passes); None when this shape has not been profiled."""
+    WRITE_SIZE passes) and that file's name; (None, None) when this shape has not been profiled."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_L{L}.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes"])
+        return float(json.load(open(files[-1]))["hbm_bytes"]), os.path.relpath(files[-1], ROOT)
     except Exception:
+        return None, None
+
+
+def clock_probe(fa, torch, q, k, v, o, seconds=0.4):
+    """Effective shader clock under THIS kernel's load, in GHz: the library's diagnostic twin
+    (libflash_attention_stamps.so: the default kernel alone, every workgroup recording s_memtime, shader cycles, and
+    s_memrealtime, 100 MHz, at entry and exit) runs the same problem back to back for `seconds`, and the clock is
+    cycles / time of the last launch's workgroups (median).  None when the twin is not built or does not serve
+    the shape."""
+    import ctypes as ct
+
+    import numpy as np
+
+    path = os.path.join(ROOT, "flash-attention_amd", "csrc", "libflash_attention_stamps.so")
+    B, H, L, Dh = q.shape
+    if not os.path.exists(path) or L % 64 or L < 320 or Dh != D:
         return None
+    twin = ct.CDLL(path)
+    twin.fa_forward.argtypes = [fa.HalfPtr] * 4 + [ct.c_int] * 5 + [ct.c_void_p, ct.POINTER(ct.c_float)]
+    twin.fa_forward.restype = ct.c_int
+    twin.fa_debug_set_stamps.argtypes = [ct.c_void_p]
+    ptr = lambda t: ct.cast(ct.c_void_p(t.data_ptr()), fa.HalfPtr)
+    stream = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: twin.fa_forward(ptr(q), ptr(k), ptr(v), ptr(o), B, H, L, Dh, 64, stream, None)
+    stamps = torch.zeros(4 * 1024, dtype=torch.int64, device=q.device)
+    twin.fa_debug_set_stamps(None)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            if call() != 0:
+                return None
+        torch.cuda.synchronize()
+    twin.fa_debug_set_stamps(ct.c_void_p(stamps.data_ptr()))
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    twin.fa_debug_set_stamps(None)
+    s = stamps.cpu().numpy().reshape(-1, 4)
+    s = s[s[:, 3] > 0]
+    if len(s) == 0:
+        return None
+    ghz = (s[:, 2] - s[:, 0]) / np.maximum(s[:, 3] - s[:, 1], 1) * 0.1
+    return {"ghz": float(np.median(ghz)), "cycles_per_workgroup": float(np.median(s[:, 2] - s[:, 0])),
+            "workgroups": int(len(s))}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -369,6 +447,49 @@ def base_result(args, world, value, wall_max):
     }
 
 
+C4_L, C4_HEADS = 16384, 16  # the long-sequence shape of the metric's multi-GPU curve: B=1, H=16, L=16384
+
+
+def strong_c4(args, fa, torch, ranks, dev):
+    """The strong-scaling point of the metric's multi-GPU curve beside the default (weak) line: the 16 heads of
+    B=1, H=16, L=16384 split over the ranks (independent (batch, head) pairs: tensor_flash_attention.cu:30-31), no
+    data-path collective.  Also times all 16 heads on this rank's GPU alone: efficiency_vs_N1_rate = the job's
+    rate per GPU over that one-GPU rate, both measured in this run."""
+    world, rank = ranks.world, ranks.rank
+    if C4_HEADS % world:
+        return {"error": f"{C4_HEADS} heads do not divide over {world} ranks"}
+    L, bh_local = C4_L, C4_HEADS // world
+    full = [torch.empty((C4_HEADS, L, D), dtype=torch.float16, device=dev) for _ in range(3)]
+    for t, seed in zip(full, (1234, 2345, 3456)):
+        fa.init_half(t, seed)
+    q, k, v = [t[rank * bh_local:(rank + 1) * bh_local].reshape(1, bh_local, L, D) for t in full]
+    o = torch.empty_like(q)
+    steps = max(3, min(20, args.steps))
+    wall, ms = time_steps(torch, lambda: fa.attention(q, k, v, out=o), steps, 2, ranks.barrier,
+                          min(args.preheat_seconds, 0.5))
+    wall_max = ranks.max(wall)
+    per_rank_ms = ranks.gather(ms)
+    flops_job = 4.0 * C4_HEADS * float(L) * float(L) * D
+    tflops_total = flops_job * steps / wall_max / 1e12
+    # the one-GPU rate on this run's own hardware: all 16 heads on every rank at the same time
+    qa, ka, va = [t.reshape(1, C4_HEADS, L, D) for t in full]
+    oa = torch.empty_like(qa)
+    _, ms_all = time_steps(torch, lambda: fa.attention(qa, ka, va, out=oa), max(3, steps // 2), 1, ranks.barrier,
+                           min(args.preheat_seconds, 0.3))
+    rate_n1 = flops_job / (ranks.max(ms_all) * 1e-3) / 1e12
+    return {
+        "workload": f"B=1 H={C4_HEADS} L={L} D={D}, heads split over the ranks",
+        "per_gpu_heads": bh_local,
+        "steps": steps,
+        "ms_max_over_ranks": wall_max / steps * 1e3,
+        "per_rank_kernel_ms": per_rank_ms,
+        "tflops_total": tflops_total,
+        "one_gpu_16_heads_tflops": rate_n1,
+        "efficiency_vs_N1_rate": tflops_total / world / rate_n1,
+        "key_split_ways": int(fa.lib().fa_split_ways(bh_local, L, L)),
+    }
+
+
 def run_selftest(args, world, rank, line):
     """No GPU, no kernel: the launcher, the process group and the line's assembly with a stand-in step."""
     import torch
@@ -384,6 +505,15 @@ def run_selftest(args, world, rank, line):
     result.update({"data": "selftest: no kernel ran (stand-in step sleeps 1 ms)", "value": None,
                    "config": {"workload": "none (launcher / process-group plumbing test)"},
                    "per_rank_kernel_ms": per_rank})
+    if world > 1 and args.scaling == "weak" and not args.no_strong_c4:
+        # the keys of the strong-scaling point, with the stand-in step in the kernel's place
+        t0 = time.perf_counter()
+        time.sleep(0.001)
+        w = ranks.max(time.perf_counter() - t0)
+        result["strong_c4"] = {"workload": "none (stand-in)", "per_gpu_heads": C4_HEADS // world if C4_HEADS % world == 0 else None,
+                               "steps": 1, "ms_max_over_ranks": w * 1e3, "per_rank_kernel_ms": ranks.gather(1.0 + rank),
+                               "tflops_total": None, "one_gpu_16_heads_tflops": None, "efficiency_vs_N1_rate": None,
+                               "key_split_ways": None}
     ranks.close()
     if rank == 0:
         line.emit(result)
@@ -459,6 +589,15 @@ def run_heads(args, fa, torch, ranks, dev):
         _, ms_n = time_steps(torch, lambda: fa.attention(qn, kn, vn, out=o), max(5, args.steps // 2), 3, lambda: None,
                              min(args.preheat_seconds, 1.0))
         result["normal_data_tflops"] = flops_local / (ms_n * 1e-3) / 1e12
+        # the effective shader clock under the kernel's load, per data set (same cycle count, different clock)
+        cn = clock_probe(fa, torch, qn, kn, vn, o)
+        cp = clock_probe(fa, torch, q, k, v, o)
+        result["clock_ghz_effective"] = cp["ghz"] if cp else None
+        result["clock_ghz_effective_normal_data"] = cn["ghz"] if cn else None
+        result["cycles_per_workgroup"] = cp["cycles_per_workgroup"] if cp else None
+        result["clock_source"] = ("s_memtime / s_memrealtime stamps of every workgroup of the default kernel's diagnostic "
+                                  "twin (libflash_attention_stamps.so) under back-to-back launches of this shape"
+                                  if cp else "diagnostic twin not built or shape not served")
         del qn, kn, vn
 
     if rank == 0 and world == 1 and not args.no_sweep:
@@ -487,6 +626,14 @@ def run_heads(args, fa, torch, ranks, dev):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(B, H, L, args.cpu_seconds)
+
+    # More than one rank and no mode flag: the same line also carries the strong-scaling point of the metric's
+    # curve.  (All ranks take part; a failure is recorded in the line instead of losing it.)
+    if ranks.dist is not None and args.scaling == "weak" and not args.no_strong_c4:
+        try:
+            result["strong_c4"] = strong_c4(args, fa, torch, ranks, dev)
+        except Exception as e:  # noqa: BLE001
+            result["strong_c4"] = {"error": f"{type(e).__name__}: {e}"}
     return result
 
 

@@ -282,11 +282,14 @@ int launch(const fa::FwdParams& base, hipStream_t stream, Workspace wsk = Worksp
     long grid = switches().persistent ? balanced_grid(items) : items;
     const KernelId kid = pick_kernel(nw, p.lq, p.lk);
     if (kid == kKernelW64 && wsk != Workspace::kNone && p.flags == 0 && switches().persistent) {
-        const int S = pick_split(p.bh, p.q_blocks, p.lq, p.lk, persistent_grid(), kSplitMaxRows);
+        // The static buffer bounds the cost model's choice (the best split that fits, or none: an unsplit launch
+        // needs no scratch at all); only a split forced with FA_SPLIT=n that does not fit is an error.
+        const bool forced = switches().split > 0;
+        const int S = pick_split(p.bh, p.q_blocks, p.lq, p.lk, persistent_grid(),
+                                 wsk == Workspace::kScratch && !forced ? kScratchRows : kSplitMaxRows);
         if (S > 1) {
             const size_t bytes = (size_t)S * p.bh * p.lq * kSplitRowBytes;
             if (wsk == Workspace::kScratch) {
-                // (the split is the one the allocating entry point would choose; it has to fit the static buffer)
                 if (bytes > kScratchBytes) {
                     std::snprintf(g_last_error, sizeof(g_last_error),
                                   "fa_forward_noalloc: this shape divides its keys %d ways and needs %zu bytes of "
@@ -826,7 +829,10 @@ int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV
     if (B <= 0 || H <= 0) return fail(FA_ERR_SHAPE, "fa_forward_varlen: B and H must be positive%s");
     if ((long)B * H > 0x7fffffffL / 64) return fail(FA_ERR_SHAPE, "fa_forward_varlen: B*H too large%s");
     if (!dQ || !dK || !dV || !dO) return fail(FA_ERR_POINTER, "fa_forward_varlen: null tensor pointer%s");
-    if (!d_q_len && !d_k_len)  // nothing is padded: the general entry point's own routes (it wants Lq == Lk under the mask)
+    // nothing is padded: the general entry point's own routes (except under the mask with Lq != Lk, which that entry
+    // point rejects and the masked kernels below take: whether a call is accepted must not depend on a length
+    // array being null)
+    if (!d_q_len && !d_k_len && !((flags & FA_FLAG_CAUSAL) && Lq != Lk))
         return fa_forward_general(dQ, dK, dV, dO, B, H, Lq, Lk, D, flags, stream_, elapsed_ms);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     fa::FwdParams p{};

@@ -65,24 +65,29 @@ RING_RESERVED_CUS = 8
 
 
 class _reserved_cus:
-    """with _reserved_cus(k): ...  (no-op for k == 0 or when a caller has already reserved units)"""
+    """with _reserved_cus(k): ...  (no-op for k == 0 or when a caller has already reserved units).
+
+    The reservation is PROCESS-WIDE (fa_set_reserved_cus stores one value per process): while the block runs,
+    attention launches from other threads or streams of this process also leave k units free.  On exit the value
+    found on entry is put back, unless somebody changed the reservation in between: then theirs stays."""
 
     def __init__(self, k):
-        self.k, self.fa, self.active = k, None, False
+        self.k, self.fa, self.before = k, None, None
 
     def __enter__(self):
         if self.k > 0:
             import flash_attention_amd as fa
 
             self.fa = fa
-            if fa.lib().fa_get_reserved_cus() == 0:
+            before = fa.lib().fa_get_reserved_cus()
+            if before == 0:
                 fa.set_reserved_cus(self.k)
-                self.active = True
+                self.before = before
         return self
 
     def __exit__(self, *exc):
-        if self.active:
-            self.fa.set_reserved_cus(0)
+        if self.before is not None and self.fa.lib().fa_get_reserved_cus() == self.k:
+            self.fa.set_reserved_cus(self.before)
         return False
 
 

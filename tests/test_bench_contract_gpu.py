@@ -36,6 +36,12 @@ def test_bench_json_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert j["normal_data_tflops"] > 0 and j["reference_protocol_tflops"] > 0 and j["pct_of_fp16_peak"] > 0
     assert j["per_rank_kernel_ms"] == [rf["kernel_ms"]] and rf["key_split_ways"] == 1
+    # provenance: where the traffic figure comes from, and the clock the kernel ran at on either data set
+    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    if rf["traffic"] is not None:
+        assert rf["traffic_source"].startswith("profiles/") and "not measured in this run" in rf["traffic_source"]
+    assert 1.0 < j["clock_ghz_effective"] < 2.6 and 1.0 < j["clock_ghz_effective_normal_data"] < 2.6
+    assert j["cycles_per_workgroup"] > 5e4 and "s_memtime" in j["clock_source"]
 
 
 def _bench(*argv, env=None, timeout=280):
@@ -82,3 +88,8 @@ def test_bench_multi_rank_code_path_with_one_rank():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["scaling"] == "weak"
+    # the multi-rank default line also carries the strong-scaling point: here one rank holds all 16 heads
+    c4 = j["strong_c4"]
+    assert "error" not in c4, c4
+    assert c4["per_gpu_heads"] == 16 and c4["key_split_ways"] == 1 and c4["tflops_total"] > 0
+    assert 0.8 < c4["efficiency_vs_N1_rate"] < 1.25  # the same 16 heads timed twice

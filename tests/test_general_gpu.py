@@ -597,6 +597,30 @@ def test_padded_batch_only_key_lengths_given(fa, oracle, dev):
     assert torch.equal(o2, fa.attention_general(q, k, v))
 
 
+@pytest.mark.parametrize("Lq,Lk", [(200, 328), (320, 192)])
+def test_causal_mask_with_different_lengths_and_no_length_arrays(fa, oracle, dev, Lq, Lk):
+    """fa_forward_varlen under the causal mask with Lq != Lk: accepted with both length arrays NULL exactly as with
+    arrays that hold the padded lengths (same kernel, same bits), and equal to the oracle's blockwise form with the
+    mask on positions from 0 (key j is visible to query i iff j <= i, testing.cu:74-77)."""
+    import torch
+
+    B, H, D = 2, 3, 128
+    rng = np.random.default_rng(31)
+    Q = rng.standard_normal((B, H, Lq, D), dtype=np.float32).astype(np.float16)
+    K = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    V = rng.standard_normal((B, H, Lk, D), dtype=np.float32).astype(np.float16)
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o_null = fa.attention_varlen(q, k, v, None, None, causal=True)
+    ql = torch.full((B,), Lq, dtype=torch.int32, device=dev)
+    kl = torch.full((B,), Lk, dtype=torch.int32, device=dev)
+    o_lens = fa.attention_varlen(q, k, v, ql, kl, causal=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o_null, o_lens)
+    st = oracle.BlockState(B, H, Lq, D)
+    oracle.block_update(st, Q, K, V, causal=True)
+    gate(oracle, oracle.block_finalize(st), o_null.cpu().numpy(), f"causal Lq={Lq} Lk={Lk}")
+
+
 # ------------------------------------------------------------------------------------------------
 # head dims 64 and 256 in whole tiles: fa_fwd_hd_kernel
 # ------------------------------------------------------------------------------------------------

@@ -242,14 +242,44 @@ def test_bench_launcher_starts_its_own_ranks():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
     assert j["per_rank_kernel_ms"] == [1.0, 2.0]  # gathered in rank order
     assert "selftest" in j["data"] and j["value"] is None  # no kernel ran and the line says so
+    # with more than one rank and no mode flag the line also carries the strong-scaling point's keys
+    c4 = j["strong_c4"]
+    for key in ("per_gpu_heads", "ms_max_over_ranks", "tflops_total", "efficiency_vs_N1_rate", "key_split_ways"):
+        assert key in c4, key
+    assert c4["per_gpu_heads"] == 8 and c4["per_rank_kernel_ms"] == [1.0, 2.0]
+
+
+def test_bench_launcher_counts_gpus_without_a_gpu_runtime(tmp_path):
+    """The launcher counts GPUs from the kernel driver's topology in sysfs (nodes with SIMDs) and imports neither
+    torch nor any HIP library before it starts the ranks: a parent that had initialised HIP would then fork and
+    exec children, which the GPU boxes refuse."""
+    import subprocess
+    import sys
+
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):  # two CPU sockets, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "assert bench.count_gpus(%r, env={}) == 3\n"
+            "assert bench.count_gpus(%r, env={'HIP_VISIBLE_DEVICES': '0,2'}) == 2\n"
+            "assert bench.count_gpus(%r + '/missing', env={}) == 0\n"
+            "import inspect; src = inspect.getsource(bench.launch_ranks)\n"
+            "assert 'import torch' not in src and 'count_gpus()' in src\n"
+            "assert not [m for m in sys.modules if m == 'torch' or m.startswith('torch.')], 'torch imported'\n"
+            % (ROOT, str(nodes), str(nodes), str(nodes)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_bench_launcher_fails_loudly_without_the_gpus():
     """Asked for more GPUs than the node has, bench.py exits non-zero and prints no JSON line (it used to run one
     rank and report n_gpus = 1)."""
-    import torch
+    sys.path.insert(0, ROOT)
+    import bench
 
-    n = torch.cuda.device_count()
+    n = bench.count_gpus()
     r = _run_bench("--gpus", str(n + 2), "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -99,6 +99,63 @@ def test_noalloc_rejects_what_does_not_fit_and_bad_arguments(fa, dev, fa_env):
     assert L_.fa_forward_noalloc(None, z, z, z, 1, 1, 64, 128, 64, None) == 5  # NULL pointer
 
 
+def test_noalloc_takes_the_best_split_that_fits_or_none(fa, oracle, dev, fa_env):
+    """Shapes whose cost-model split would not fit the static buffer (B=1, H=1, L=7744: eleven ranges of 85 184
+    rows; B=1, H=3, L=24576: three ranges of 221 184 rows) are no error: the entry point takes the best split that
+    fits, or launches undivided, which needs no scratch at all.  Checked against the oracle on sampled rows."""
+    import torch
+
+    fa_env(FA_SPLIT=None)
+    for shape, seed in (((1, 1, 7744, 128), 21), ((1, 3, 24576, 128), 22)):
+        q, k, v = _inputs(dev, seed, shape)
+        o = torch.full_like(q, float("nan"))
+        rc = _call(fa, "fa_forward_noalloc", q, k, v, o)
+        assert rc == 0, (shape, rc, fa.lib().fa_last_error())
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all(), shape
+        rows = np.unique(np.linspace(0, shape[2] - 1, 16).astype(np.int32))
+        ref = oracle.attention_cpu_rows(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), rows)
+        m = oracle.error_metrics(ref, o[:, :, rows].cpu().numpy())
+        assert m["max_abs"] <= 2e-3 and m["global_rel"] <= 1e-3, (shape, m)
+
+
+def test_noalloc_allocates_nothing(fa, dev, fa_env):
+    """The stream-ordered pool's high-water mark of used memory, reset before the call: fa_forward on a shape that
+    divides its keys raises it (its workspace comes from that pool; this shows the probe sees an allocation),
+    fa_forward_noalloc on the same shape leaves it at zero."""
+    import torch
+
+    fa_env(FA_SPLIT=None)
+    hip = ct.CDLL("libamdhip64.so")
+    pool = ct.c_void_p()
+    assert hip.hipDeviceGetDefaultMemPool(ct.byref(pool), 0) == 0
+    kUsedMemHigh = 8  # hipMemPoolAttrUsedMemHigh
+
+    def reset():
+        zero = ct.c_uint64(0)
+        assert hip.hipMemPoolSetAttribute(pool, kUsedMemHigh, ct.byref(zero)) == 0
+
+    def high():
+        val = ct.c_uint64(0)
+        assert hip.hipMemPoolGetAttribute(pool, kUsedMemHigh, ct.byref(val)) == 0
+        return val.value
+
+    q, k, v = _inputs(dev, 5, (1, 2, 8192, 128))
+    assert fa.lib().fa_split_ways(2, 8192, 8192) > 1
+    o = torch.empty_like(q)
+    assert _call(fa, "fa_forward_noalloc", q, k, v, o) == 0  # (first call on the device done)
+    torch.cuda.synchronize()
+    reset()
+    assert _call(fa, "fa_forward", q, k, v, o) == 0
+    torch.cuda.synchronize()
+    assert high() > 0, "the probe does not see fa_forward's workspace"
+    reset()
+    for _ in range(3):
+        assert _call(fa, "fa_forward_noalloc", q, k, v, o) == 0
+    torch.cuda.synchronize()
+    assert high() == 0, high()
+
+
 def test_split_shapes_under_stream_capture(fa, dev, fa_env):
     """A shape that divides its keys, captured in a graph: fa_forward launches it unsplit there (no allocation inside a
     capture), fa_forward_noalloc launches the split form on the static scratch buffer; both replay to the eager bits."""

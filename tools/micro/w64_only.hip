@@ -1,7 +1,8 @@
-// Experiment build of the default kernel alone: fa_forward with the library's signature, launching
-// fa::fa_fwd_w64_kernel on whole-tile shapes and nothing else.  Compiles in a fraction of the library's time;
-// tools/ab.py, tools/clock.py and tools/stamps_w64.py load it beside the product library.
-//   tools/build_w64_only.sh NAME [-DFLAG ...]  ->  build_ab/NAME.so, build_ab/NAME.s
+// The default kernel alone: fa_forward with the library's signature, launching fa::fa_fwd_w64_kernel on whole-tile
+// shapes (L >= 320) and nothing else.  Two uses: the library's diagnostic twin (csrc/Makefile `stamps`: built
+// with -DFA_STAMPS, bench.py's clock probe reads its per-workgroup stamps) and quick experiment builds, which
+// compile in a fraction of the library's time (tools/build_w64_only.sh NAME [-DFLAG ...] -> build_ab/NAME.so, .s;
+// tools/ab.py, tools/clock.py and tools/stamps_w64.py load them beside the product library).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,7 +22,7 @@ void fa_debug_set_grid(int g) { g_grid_max = g; }
 
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L, int D,
                int tile, void* stream, float* elapsed_ms) {
-    if (D != 128 || tile != 64 || L % 64 || L < 320 || elapsed_ms && false) return 1;
+    if (D != 128 || tile != 64 || L % 64 || L < 320) return 1;
     fa::FwdParams p = {};
     p.q = reinterpret_cast<const fa::half_t*>(dQ);
     p.k = reinterpret_cast<const fa::half_t*>(dK);
