@@ -1040,6 +1040,21 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             decode(it, nh, nb);
         }
     };
+    // The step in which a workgroup sends for the next item's Q rows.  The staging image is free from the item's
+    // second step on and the rows are needed in its last one, so any step from 1 to n_tiles - 2 will do; which
+    // one depends on the workgroup: with equal items all workgroups of a launch reach their item boundaries
+    // together, and sent in the same step everywhere the rows are one burst of 64 KB per compute unit (17 MB
+    // across the chip at L = 512) that HBM serves in more than a microsecond while every wave waits (cycle stamps:
+    // that step took 2 000 - 2 900 cycles longer than its neighbours, the same time at either clock).  Spread
+    // over up to six steps by workgroup (bits 3-5 of its id: the XCDs stay mixed) the bursts are a sixth each.
+#ifndef W64_Q_SPREAD
+#define W64_Q_SPREAD 6
+#endif
+    const int q_class = (int)((blockIdx.x >> 3) % W64_Q_SPREAD);
+    auto q_step = [&]() -> int {
+        const int room = n_tiles - 3;  // steps before the last but one that may take it
+        return n_tiles - 2 - (q_class < room ? q_class : room);
+    };
     [[maybe_unused]] const unsigned img_lds =
         __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)img);
     int nhead = head, nqb = qb;  // the next item, known from its last-but-one step on
@@ -1124,12 +1139,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
                 dma_piece_at<1024 * e>(x_src, d_koff[e]);
             }
         };
-        // ---- in the last-but-one step: the next item's Q rows.  The load cursor, three tiles ahead, is on the
-        //      next item's third tile by then: that item's head and block are the cursor's (kept for the last step,
-        //      by which the cursor may have moved on to the item after).
-        if (!QSTREAM && __builtin_expect(more_items && (t + 2 == n_tiles), 0)) {
-            nhead = kc.head;
-            nqb = kc.qb;
+        // ---- the next item's Q rows, once per item, in step q_step() (see there); the item's head and block are
+        //      kept for the item's last step, which installs the rows.
+        if (!QSTREAM && __builtin_expect(more_items && (t == q_step()), 0)) {
+            next_of(head, qb, next_item, nhead, nqb);
             nwrow = source_row(nhead, nqb);
 #ifndef FA_ABLATE_NO_QDMA  // (timing experiments only: wrong results)
             const size_t qsrc = q_row(nhead, nqb);

@@ -16,6 +16,9 @@
 #include <string>
 
 #include "fa_fwd_kernel.hpp"
+#ifdef FA_AB_KERNELS
+#include "fa_fwd_staged_kernel.hpp"
+#endif
 #include "fa_fwd_ring_kernel.hpp"
 #include "fa_fwd_w64_kernel.hpp"
 #include "fa_fwd_general_kernel.hpp"
@@ -173,9 +176,14 @@ constexpr size_t kSplitMaxRows = 262144;  // virtual rows a split launch may tak
 // 65536 virtual rows (B = 1, H = 2, L = 16384 in two ranges; H = 1 in four) = 34 078 720 bytes, held by every
 // GPU the library runs on until the process ends.  `scratch` is a host-side stand-in for the array, not a device
 // address: host code only ever uses the per-device pointer that scratch_ptr() obtains from the runtime.
-constexpr size_t kScratchRows = 65536;
+// (-DFA_NOALLOC_SCRATCH_ROWS=n sizes it at build time; 0 leaves a token array, and fa_forward_noalloc then never
+// divides a launch's keys: for deployments that do not want every process that loads the library to hold 34 MB per GPU.)
+#ifndef FA_NOALLOC_SCRATCH_ROWS
+#define FA_NOALLOC_SCRATCH_ROWS 65536
+#endif
+constexpr size_t kScratchRows = FA_NOALLOC_SCRATCH_ROWS;
 constexpr size_t kScratchBytes = kScratchRows * kSplitRowBytes;
-static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+static __device__ __align__(256) unsigned char scratch[kScratchBytes > 0 ? kScratchBytes : 256];
 
 // The array's address on the current device (every GPU holds its own copy at its own address), looked up
 // once per device with that device current.  nullptr (and the error text set) on failure.

@@ -14,6 +14,9 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink
     __shared__ float lds[64 * 1024 / 4];
     float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f, a4 = 4.f, a5 = 5.f, a6 = 6.f, a7 = 7.f, y = 0.5f;
     unsigned u0 = threadIdx.x * 8, u1 = 1;
+    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+    h8_t h8 = {1, 2, 3, 4, 5, 6, 7, 8};
+    asm volatile("" : "+v"(h8));
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(y), "+v"(u0), "+v"(u1));
     asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_write_b32 a1, %0\n v_accvgpr_write_b32 a2, %0\n v_accvgpr_write_b32 a3, %0" ::"v"(y) : "a0", "a1", "a2", "a3");
     __syncthreads();
@@ -64,6 +67,25 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink
                            "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
                            : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&a0));)
     }
+    else if constexpr (KIND == 11) {  // v_exp_f32 and v_mul_f32 alternating, independent
+        REP16(asm volatile("v_exp_f32 %0, %0\n v_mul_f32 %4, %4, %8\n v_exp_f32 %1, %1\n v_mul_f32 %5, %5, %8\n v_exp_f32 %2, %2\n v_mul_f32 %6, %6, %8\n v_exp_f32 %3, %3\n v_mul_f32 %7, %7, %8\n"
+                           "v_exp_f32 %0, %0\n v_mul_f32 %4, %4, %8\n v_exp_f32 %1, %1\n v_mul_f32 %5, %5, %8\n v_exp_f32 %2, %2\n v_mul_f32 %6, %6, %8\n v_exp_f32 %3, %3\n v_mul_f32 %7, %7, %8"
+                           : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));)
+    } else if constexpr (KIND == 12) {  // one MFMA 32x32x16 per 7 independent v_mul (8 instructions per group)
+        REP16(asm volatile("v_mfma_f32_32x32x16_f16 a[16:31], %8, %8, a[16:31]\n v_mul_f32 %0, %0, %9\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %9\n v_mul_f32 %3, %3, %9\n v_mul_f32 %4, %4, %9\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %9\n"
+                           "v_mfma_f32_32x32x16_f16 a[32:47], %8, %8, a[32:47]\n v_mul_f32 %0, %0, %9\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %9\n v_mul_f32 %3, %3, %9\n v_mul_f32 %4, %4, %9\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %9"
+                           : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(h8), "v"(y)
+                           : "a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47");)
+    } else if constexpr (KIND == 13) {  // MFMA 32x32x16 alone, two accumulators alternating
+        REP16(asm volatile(".rept 8\n v_mfma_f32_32x32x16_f16 a[16:31], %0, %0, a[16:31]\n v_mfma_f32_32x32x16_f16 a[32:47], %0, %0, a[32:47]\n .endr"
+                           : : "v"(h8)
+                           : "a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47");)
+    } else if constexpr (KIND == 14) {  // one MFMA per 3 v_mul + 1 v_exp + 1 v_add-like (the phase's mix: 6 per group)
+        REP16(asm volatile(".rept 4\n v_mfma_f32_32x32x16_f16 a[16:31], %8, %8, a[16:31]\n v_fma_f32 %0, %0, %9, %9\n v_exp_f32 %1, %1\n v_add_f32 %2, %2, %9\n v_cvt_pk_f16_f32 %3, %4, %5\n"
+                           "v_mfma_f32_32x32x16_f16 a[32:47], %8, %8, a[32:47]\n v_fma_f32 %4, %4, %9, %9\n v_exp_f32 %5, %5\n v_add_f32 %6, %6, %9\n .endr"
+                           : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(h8), "v"(y)
+                           : "a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47");)
+    }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)");
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
@@ -95,5 +117,9 @@ int main() {
     run<8>("s_add_u32 dependent", d_out, d_sink);
     run<9>("s_bitcmp1 + s_cbranch (not taken) x256 pairs", d_out, d_sink);
     run<10>("v_pk_mul_f32", d_out, d_sink);
+    run<11>("v_exp_f32 / v_mul_f32 alternating", d_out, d_sink);
+    run<12>("1 MFMA + 7 v_mul per group (x32)", d_out, d_sink);
+    run<13>("MFMA 32x32x16 alone (x256)", d_out, d_sink);
+    run<14>("MFMA + fma, exp, add, (cvt) mix (x72 groups of ~4.5)", d_out, d_sink);
     return 0;
 }
