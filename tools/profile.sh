@@ -6,7 +6,7 @@
 #   4. WRITE_SIZE                    (HBM write side; 2 TCC slots)
 # Counter passes never share a run with tracing.  Every pass runs the SAME command, preheat included, so that
 # the counters and the durations describe launches at the same clock.  Results land in gpurun_out/prof_<TAG>/.
-#   tools/profile.sh L [STEPS] [TAG] [extra bench.py arguments, e.g. --data normal]
+#   [PREHEAT=seconds] tools/profile.sh L [STEPS] [TAG] [extra bench.py arguments, e.g. --data normal]
 set -uo pipefail
 L=${1:-512}
 STEPS=${2:-20}
@@ -16,7 +16,7 @@ cd "$(dirname "${BASH_SOURCE[0]}")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD=(python3 bench.py --seq-len "$L" --steps "$STEPS" --warmup 5 --preheat-seconds 0.5 --no-cpu-baseline --no-sweep --no-extras "$@")
+CMD=(python3 bench.py --seq-len "$L" --steps "$STEPS" --warmup 5 --preheat-seconds "${PREHEAT:-0.5}" --no-cpu-baseline --no-sweep --no-extras "$@")
 echo "${CMD[*]}" > "$OUT/command.txt"
 
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "${CMD[@]}" > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
