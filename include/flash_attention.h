@@ -74,9 +74,10 @@ enum {
 /* Same work and arguments as run_tensor_flash_attention, but returns a status
  * instead of throwing; the two drop-in functions are thin shells over these.
  *
- * Launches with fewer (head, 256-row query block) items than the device has compute units (few heads and a
- * long sequence: B*H*ceil(L/256) < 256, e.g. one rank's two heads of B=1, H=16, L=16384 sharded over eight
- * GPUs) divide every head's keys into ranges, run the ranges as heads of their own and fold them with a
+ * Launches with fewer (head, 256-row query block) items than TWICE the resident workgroups (one per compute unit,
+ * less fa_set_reserved_cus) may divide every head's keys into ranges when a cost model says it pays
+ * (fa_split_ways() is the authority; typically few heads and a long sequence, e.g. one rank's two heads of B=1,
+ * H=16, L=16384 sharded over eight GPUs: 128 items on 256 units): they run the ranges as heads of their own and fold them with a run the ranges as heads of their own and fold them with a
  * second, small kernel.  The reference never meets this: its grid is (L/64, B, H) workgroups of 64 rows
  * (wrapper.cu:74-76).  The workspace (520 bytes per query row and range) is taken from the stream's memory pool
  * (hipMallocAsync / hipFreeAsync: stream-ordered, no device synchronisation) and returned to it by the same call;
@@ -89,12 +90,15 @@ int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t*
 
 /* fa_forward for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
  * harnesses that forbid it.  No counterpart in the reference.  Same arguments, result and kernels as fa_forward
- * (bit-identical output) minus elapsed_ms; it calls no hipMalloc / hipFree / hipMallocAsync or any other allocating
+ * minus elapsed_ms; it calls no hipMalloc / hipFree / hipMallocAsync or any other allocating
  * routine, creates no events and never waits.  A launch that divides its keys (see fa_forward) takes its workspace
  * from a buffer of 34 078 720 bytes that is part of the library's device image (65 536 query rows x ranges: B*H*L*S
  * <= 65536, e.g. B=1, H=2, L=16384 in two ranges); every GPU the library runs on holds that buffer until the
- * process ends.  A shape whose split needs more returns FA_ERR_WORKSPACE with the sizes in fa_last_error() and
- * launches nothing; shapes that need no split (most: B*H*ceil(L/256) >= 512) use no scratch at all.  All calls on
+ * process ends.  The cost model is bounded by that buffer: the entry point takes the best split that fits, or launches
+ * undivided (which needs no scratch at all; most shapes: a launch is only ever divided when it has fewer
+ * (head, 256-row block) items than twice the resident workgroups, see fa_split_ways), so its output has fa_forward's
+ * bits whenever both choose the same split and passes the same parity gate otherwise.  Only a split FORCED with
+ * FA_SPLIT=n that does not fit returns FA_ERR_WORKSPACE (sizes in fa_last_error()) and launches nothing.  All calls on
  * one GPU share the buffer: two calls that divide their keys and overlap in time on one GPU (different streams
  * or host threads) race on it; calls on one stream are ordered and safe.  The first call on a device looks
  * the buffer's address up and must not be made under stream capture. */
