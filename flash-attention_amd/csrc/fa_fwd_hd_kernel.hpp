@@ -375,6 +375,8 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         if constexpr (STATE)
             if (p.k_splits > 1) lk_v = min(max(lk_v - key_first, 0), p.lk_split);
         if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
+        // (a padded batch whose long sequences run on fa_fwd_w64_varlen_kernel, launched beside this one)
+        if (p.long_q > 0 && lq_v >= p.long_q && lk_v >= p.long_k) return;
     }
     const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
     const bool wave_valid = q_row0 < lq_v;              // a wave past the last row computes along and stores nothing

@@ -85,6 +85,13 @@ struct FwdParams {
     const int* q_len;
     const int* k_len;
     int heads_per_batch;
+    // Padded batches at D = 128, long sequences on the tuned kernel (fa_fwd_w64_varlen_kernel): a device-built list of
+    // work items, four ints each (head, 256-row block, the sequence's query rows, its keys), and their number; the
+    // 128-row kernel, launched beside it for the batch's other sequences, leaves alone every sequence with at least
+    // long_q query rows and long_k keys (0: none)
+    const int* varlen_items;
+    const int* varlen_count;
+    int long_q, long_k;
 };
 
 // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second.

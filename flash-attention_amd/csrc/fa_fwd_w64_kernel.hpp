@@ -684,10 +684,16 @@ __device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int thr, int
 //     four steps that carry them run 150 - 250 cycles longer and every other step 80: +1 % at L = 448 and 512,
 //     nothing at 640 - 1024, -1 ... 2 % from 1280 on.  Not instantiated in the library; -DW64_QSTREAM_DEFAULT=true
 //     builds the plain kernel in this form (tools/build_w64_only.sh).
-template <bool CAUSAL, bool RAGGED, bool SPLIT = false, bool QSTREAM = false>
+//   VARLEN (with RAGGED, no mask) takes its items from a list in device memory instead of numbering them: entry i =
+//     (head, 256-row block, query rows, keys) of a padded batch's sequence, so that every item has its own lengths
+//     (tile count, shifted last tile, last query rows) while the strides stay the padded ones; *p.varlen_count
+//     items.  For the long sequences of fa_forward_varlen's batches; the list is built on the device by
+//     fa_varlen_plan_kernel, because the lengths live there.
+template <bool CAUSAL, bool RAGGED, bool SPLIT = false, bool QSTREAM = false, bool VARLEN = false>
 __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     static_assert(!SPLIT || (!CAUSAL && !RAGGED), "the key split is built for whole tiles without a mask");
     static_assert(!QSTREAM || (!CAUSAL && !RAGGED && !SPLIT), "Q streaming is built for the plain form");
+    static_assert(!VARLEN || (RAGGED && !CAUSAL && !SPLIT && !QSTREAM), "per-item lengths are built on the ragged form");
     constexpr bool MASKED = CAUSAL || RAGGED;
     constexpr int NWAVES = 4;
     constexpr int QB = 256;                        // query rows per item
@@ -724,10 +730,27 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w.v_ad[i] = v_lds + (unsigned)g.v_rd[i];
 
-    const int n_items = p.bh * p.q_blocks;
+    const int n_items = VARLEN ? *p.varlen_count : p.bh * p.q_blocks;
+    if constexpr (VARLEN)
+        if ((int)blockIdx.x >= n_items) return;  // (uniform, before the first transfer or barrier)
+    // (VARLEN: tile counts, the last tile's shift and the lengths are per item: *_c of the item being computed, kc.* of
+    // the load cursor's, n* of the next one; everywhere else they are the launch's)
     const int n_tiles_all = SPLIT ? p.lk_split / kKvTile : RAGGED ? (p.lk + kKvTile - 1) / kKvTile : p.lk / kKvTile;  // >= 3
     constexpr bool causal = CAUSAL;
-    [[maybe_unused]] const int dup = RAGGED ? n_tiles_all * kKvTile - p.lk : 0;
+    [[maybe_unused]] std::conditional_t<VARLEN, int, const int> dup = RAGGED ? n_tiles_all * kKvTile - p.lk : 0;
+    [[maybe_unused]] int lq_c = p.lq, lk_c = p.lk;  // VARLEN: of the item being computed
+    [[maybe_unused]] int nlq = p.lq, nlk = p.lk;    // VARLEN: of the next item
+    // one list entry: head, block, query rows, keys
+    [[maybe_unused]] auto list_item = [&](int it, int& hd, int& blk, int& lq_, int& lk_) {
+        const int* e = p.varlen_items + 4 * (size_t)it;
+        hd = e[0];
+        blk = e[1];
+        lq_ = e[2];
+        lk_ = e[3];
+    };
+#define W64_LQ_C (VARLEN ? lq_c : p.lq)
+#define W64_LQ_N (VARLEN ? nlq : p.lq)
+#define W64_LK_C (VARLEN ? lk_c : p.lk)
     const int stride = (int)gridDim.x;
     // tiles of an item: all of them, or with the mask those up to the query block's diagonal (>= 3 as well)
     auto item_tiles = [&](int blk) -> int {
@@ -764,6 +787,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         int item, tile, nt;  // nt: tiles of the cursor's item
         size_t off;
         int head, qb;  // of the cursor's item
+        int dup;       // VARLEN: rows its last tile repeats
     };
     // Items advance by `stride`, so (head, block) of the next item follow from the current ones without a
     // division (an emulated one costs about 220 cycles at every item boundary).  With the XCD-aware numbering
@@ -784,14 +808,24 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     }
 #define W64_ADVANCE(cur_)                                                                      \
     do {                                                                                       \
-        if (__builtin_expect((cur_).tile + 1 < (CAUSAL ? (cur_).nt : n_tiles_all), 1)) {       \
+        if (__builtin_expect((cur_).tile + 1 < ((CAUSAL || VARLEN) ? (cur_).nt : n_tiles_all), 1)) { \
             ++(cur_).tile;                                                                     \
             (cur_).off += kTileElems;                                                          \
-            if (RAGGED && (cur_).tile == n_tiles_all - 1) (cur_).off -= (size_t)dup * kHeadDim; \
+            if (VARLEN) {                                                                      \
+                if ((cur_).tile == (cur_).nt - 1) (cur_).off -= (size_t)(cur_).dup * kHeadDim; \
+            } else if (RAGGED && (cur_).tile == n_tiles_all - 1) {                             \
+                (cur_).off -= (size_t)dup * kHeadDim;                                          \
+            }                                                                                  \
         } else if ((cur_).item + stride < n_items) {                                           \
             (cur_).item += stride;                                                             \
             (cur_).tile = 0;                                                                   \
-            if (!CAUSAL && inc_wrap != 0) {                                                    \
+            if (VARLEN) {                                                                      \
+                int lq_, lk_;                                                                  \
+                list_item((cur_).item, (cur_).head, (cur_).qb, lq_, lk_);                      \
+                (cur_).nt = (lk_ + kKvTile - 1) / kKvTile;                                     \
+                (cur_).dup = (cur_).nt * kKvTile - lk_;                                        \
+                (cur_).off = kv_base((cur_).head);                                             \
+            } else if (!CAUSAL && inc_wrap != 0) {                                             \
                 (cur_).qb += inc_qb;                                                           \
                 (cur_).head += inc_head;                                                       \
                 if ((cur_).qb >= p.q_blocks) {                                                 \
@@ -801,8 +835,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             } else {                                                                           \
                 decode((cur_).item, (cur_).head, (cur_).qb);                                   \
             }                                                                                  \
-            (cur_).nt = item_tiles((cur_).qb);                                                 \
-            (cur_).off = kv_base((cur_).head);                                                 \
+            if (!VARLEN) {                                                                     \
+                (cur_).nt = item_tiles((cur_).qb);                                             \
+                (cur_).off = kv_base((cur_).head);                                             \
+            }                                                                                  \
         }                                                                                      \
     } while (0)
 #define W64_DMA_K(slot_)                                                                       \
@@ -827,49 +863,58 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     // ---- compute stream: first item
     int item = blockIdx.x;
     int head, qb;
-    decode(item, head, qb);
-    std::conditional_t<CAUSAL, int, const int> n_tiles = item_tiles(qb);  // of the item being computed
+    if constexpr (VARLEN) {
+        list_item(item, head, qb, lq_c, lk_c);
+        nlq = lq_c;
+        nlk = lk_c;
+    } else {
+        decode(item, head, qb);
+    }
+    std::conditional_t<CAUSAL || VARLEN, int, const int> n_tiles =
+        VARLEN ? (lk_c + kKvTile - 1) / kKvTile : item_tiles(qb);  // of the item being computed
+    if constexpr (VARLEN) dup = n_tiles * kKvTile - lk_c;
     // A wave's 64 rows of a query block, or, when the block is the sequence's last and ends before them
     // (lq is a multiple of 64, not necessarily of 256), the block's first 64 rows as a stand-in source:
     // such a wave computes along (it moves its share of every tile and meets every barrier) and stores
     // nothing.  kNoRows marks "no rows to store".
     constexpr size_t kNoRows = ~(size_t)0;
     // position (row within the head) of the first of the 64 rows this wave computes for block blk
-    auto row_pos = [&](int blk) -> int {
+    // (lq_: the rows of the item's sequence; p.lq is the stride between heads either way)
+    auto row_pos = [&](int blk, int lq_) -> int {
         int r0 = blk * QB + wave * 64;
-        if (r0 >= p.lq) r0 = blk * QB;
+        if (r0 >= lq_) r0 = blk * QB;
         if constexpr (RAGGED)
-            if (r0 > p.lq - 64) r0 = p.lq - 64;
+            if (r0 > lq_ - 64) r0 = lq_ - 64;
         return r0;
     };
-    auto source_row = [&](int hd, int blk) -> size_t { return (size_t)hd * p.lq + (size_t)row_pos(blk); };
+    auto source_row = [&](int hd, int blk, int lq_) -> size_t { return (size_t)hd * p.lq + (size_t)row_pos(blk, lq_); };
     // where those rows' Q comes from: the same place, except that a virtual head (SPLIT) reads its real head's
-    auto q_row = [&](int hd, int blk) -> size_t {
+    auto q_row = [&](int hd, int blk, int lq_) -> size_t {
         if constexpr (SPLIT)
-            return (size_t)(hd % p.bh_real) * p.lq + (size_t)row_pos(blk);
+            return (size_t)(hd % p.bh_real) * p.lq + (size_t)row_pos(blk, lq_);
         else
-            return source_row(hd, blk);
+            return source_row(hd, blk, lq_);
     };
-    auto owns_rows = [&](int blk) -> bool { return blk * QB + wave * 64 < p.lq; };
+    auto owns_rows = [&](int blk, int lq_) -> bool { return blk * QB + wave * 64 < lq_; };
     // rows at the head of the wave's 64 that another wave owns (RAGGED, last rows of the sequence)
-    [[maybe_unused]] auto rows_skipped = [&](int blk) -> int { return blk * QB + wave * 64 - row_pos(blk); };
-    size_t wrow = source_row(head, qb);  // this wave's first query row (where its output or state goes)
-    Cursor kc = {item, 0, n_tiles, kv_base(head), head, qb};
+    [[maybe_unused]] auto rows_skipped = [&](int blk, int lq_) -> int { return blk * QB + wave * 64 - row_pos(blk, lq_); };
+    size_t wrow = source_row(head, qb, W64_LQ_C);  // this wave's first query row (where its output or state goes)
+    Cursor kc = {item, 0, n_tiles, kv_base(head), head, qb, dup};
     // Causal mask: `lim` is the position of the wave's first query row (in keys); a tile whose last key
     // lies beyond a sub-block's first row takes the mask (mask_scores, between the phases).
-    [[maybe_unused]] int lim = row_pos(qb);
+    [[maybe_unused]] int lim = row_pos(qb, W64_LQ_C);
     // needs_mask(tile, pos): does tile `tile` need a mask for the sub-block whose first row has position pos
     // (wave-uniform; the ragged last tile, or a tile the diagonal touches)?  apply_mask() then masks the
     // scores and recomputes their row max.  The call sites mark the branch unlikely, which keeps the mask
     // code out of the steady-state loop's layout.
     [[maybe_unused]] auto needs_mask = [&](int tile, int pos) -> bool {
-        const bool tail = RAGGED && dup != 0 && tile == n_tiles_all - 1;
-        const int key0 = tail ? p.lk - kKvTile : kKvTile * tile;
+        const bool tail = RAGGED && dup != 0 && tile == (VARLEN ? n_tiles : n_tiles_all) - 1;
+        const int key0 = tail ? W64_LK_C - kKvTile : kKvTile * tile;
         return tail || (causal && key0 + 63 > pos);
     };
     [[maybe_unused]] auto apply_mask = [&](f32x16& s0, f32x16& s1, float& mx, int tile, int pos) {
-        const bool tail = RAGGED && dup != 0 && tile == n_tiles_all - 1;
-        const int key0 = tail ? p.lk - kKvTile : kKvTile * tile;
+        const bool tail = RAGGED && dup != 0 && tile == (VARLEN ? n_tiles : n_tiles_all) - 1;
+        const int key0 = tail ? W64_LK_C - kKvTile : kKvTile * tile;
         const int l_ = opaque(lane);
         const int r_ = l_ & 31, h4_ = 4 * (l_ >> 5);
         if (tail)
@@ -883,7 +928,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     //        V(1), K(2)                | stay in flight: nothing reads them before step 1, and the wait at
     //                                    the end of step 0 covers them
     {
-        const size_t qsrc = q_row(head, qb);
+        const size_t qsrc = q_row(head, qb, W64_LQ_C);
         dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
         W64_DMA_K(0);
         dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
@@ -1029,7 +1074,9 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     int t = 0;
     // (head, block) of item `it` = the item after (hd, blk) in this workgroup's sequence
     [[maybe_unused]] auto next_of = [&](int hd, int blk, int it, int& nh, int& nb) {
-        if (!CAUSAL && inc_wrap != 0) {
+        if constexpr (VARLEN) {
+            list_item(it, nh, nb, nlq, nlk);
+        } else if (!CAUSAL && inc_wrap != 0) {
             nb = blk + inc_qb;
             nh = hd + inc_head;
             if (nb >= p.q_blocks) {
@@ -1123,12 +1170,12 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         if constexpr (QSTREAM) {
             if (__builtin_expect(t == 1 && more_items, 0)) {
                 next_of(head, qb, next_item, nhead, nqb);
-                nwrow = source_row(nhead, nqb);
+                nwrow = source_row(nhead, nqb, W64_LQ_N);
             }
             if (more_items && t >= 1 && t <= 4) {
                 // group t - 1 of the next item's 64 rows: 16 rows, 4 KiB on both sides
                 x_base = img_lds + 4096u * (unsigned)(t - 1);
-                x_src = p.q + (q_row(nhead, nqb) + (size_t)(16 * (t - 1))) * kHeadDim - (size_t)wave * 2048;
+                x_src = p.q + (q_row(nhead, nqb, W64_LQ_N) + (size_t)(16 * (t - 1))) * kHeadDim - (size_t)wave * 2048;
             }
         }
         auto xdma_step = [&](auto gc) {
@@ -1143,9 +1190,9 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         //      kept for the item's last step, which installs the rows.
         if (!QSTREAM && __builtin_expect(more_items && (t == q_step()), 0)) {
             next_of(head, qb, next_item, nhead, nqb);
-            nwrow = source_row(nhead, nqb);
+            nwrow = source_row(nhead, nqb, W64_LQ_N);
 #ifndef FA_ABLATE_NO_QDMA  // (timing experiments only: wrong results)
-            const size_t qsrc = q_row(nhead, nqb);
+            const size_t qsrc = q_row(nhead, nqb, W64_LQ_N);
             dma_q_rows_asm(p.q + qsrc * kHeadDim, img, lane);
             dma_q_rows_asm(p.q + (qsrc + 32) * kHeadDim, img + 32 * kRowBytes, lane);
 #endif
@@ -1174,8 +1221,8 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             // O_B of the previous item is complete: write it out, then start the new item's state
             bool zeroed;
             W64_WRITE_OUT(kAccB, rb, out_b, 32, img + 32 * kRowBytes, skip_b, true, zeroed);
-            out_b = owns_rows(qb) ? wrow : kNoRows;
-            if constexpr (RAGGED) skip_b = rows_skipped(qb);
+            out_b = owns_rows(qb, W64_LQ_C) ? wrow : kNoRows;
+            if constexpr (RAGGED) skip_b = rows_skipped(qb, W64_LQ_C);
             W64_INIT(kAccB, rb, wrow + 32, mx_b, need_b, img + 32 * kRowBytes, zeroed);
         }
         rescale_if_needed<kAccB>(need_b, mx_b, rb);
@@ -1197,7 +1244,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #endif
         if constexpr (MASKED) {
             // S_A(t+1), or in an item's last step S_A(0) of the next item: rows lim .. lim + 31
-            const int tile_a = last ? 0 : t + 1, pos_a = last ? row_pos(nqb) : lim;
+            const int tile_a = last ? 0 : t + 1, pos_a = last ? row_pos(nqb, W64_LQ_N) : lim;
             if (__builtin_expect(needs_mask(tile_a, pos_a), 0)) {
                 apply_mask(sa0, sa1, mx_a, tile_a, pos_a);
                 need_a = rescale_needed(mx_a, ra.m_run);
@@ -1205,7 +1252,8 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         }
         if (__builtin_expect(last, 0)) {
             bool zeroed;
-            W64_WRITE_OUT(kAccA, ra, (owns_rows(qb) ? wrow : kNoRows), 0, img, rows_skipped(qb), more_items, zeroed);
+            W64_WRITE_OUT(kAccA, ra, (owns_rows(qb, W64_LQ_C) ? wrow : kNoRows), 0, img, rows_skipped(qb, W64_LQ_C),
+                          more_items, zeroed);
             if (!more_items) {
                 // B is half a tile behind: O_B += V(T-1).P_B(T-1), then its rows
                 pv_only<kAccB>(pb);
@@ -1263,7 +1311,13 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             qb = nqb;
             wrow = nwrow;
             if constexpr (CAUSAL) n_tiles = item_tiles(qb);
-            if constexpr (MASKED) lim = row_pos(qb);
+            if constexpr (VARLEN) {
+                lq_c = nlq;
+                lk_c = nlk;
+                n_tiles = (lk_c + kKvTile - 1) / kKvTile;
+                dup = n_tiles * kKvTile - lk_c;
+            }
+            if constexpr (MASKED) lim = row_pos(qb, W64_LQ_C);
             t = -1;
         }
         ++t;
@@ -1291,6 +1345,98 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_kernel(const FwdPara
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_causal_kernel(const FwdParams p) {
     fa_fwd_w64_body<true, true>(p);
 }
+// The ragged form over a device-built list of items with their own lengths (see VARLEN above).
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_varlen_kernel(const FwdParams p) {
+    fa_fwd_w64_body<false, true, false, false, true>(p);
+}
+// The item list of fa_fwd_w64_varlen_kernel, built where the lengths live.  One workgroup: per sequence the valid
+// lengths (clamped to the padded ones; a null array means the padded length), whether the tuned kernel takes the
+// sequence (at least long_q query rows and long_k keys) and its number of items H * ceil(q / 256); the sequences
+// in descending order of keys (an item's cost; batches of up to kVarlenSortMax sequences, larger ones keep their
+// order); a scan over them; then every thread writes its share of the entries (head, block, query rows, keys).
+// Within a sequence the heads go in groups of eight with the group's blocks interleaved (block 0 of heads 0-7,
+// block 1 of heads 0-7, ...): with H a multiple of 8 an entry's index is then congruent to its head mod 8,
+// workgroup ids congruent mod 8 share an XCD, and a head's K/V stay in one L2, as in decode_item.
+// Workgroup w of `grid` takes entries w, w + grid, ...: the entries are laid down in rounds of `grid`, every other
+// round back to front (the last one forwards, so that it has no holes), which hands the workgroup with the
+// costliest item of one round the cheapest of the next.  With a few items per workgroup whose costs differ by a
+// factor of three, the busiest workgroup then carries 7 - 10 % more than the mean instead of 15 - 18 %.
+constexpr int kVarlenMaxBatch = 4096;
+constexpr int kVarlenSortMax = 512;
+__global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restrict__ q_len, const int* __restrict__ k_len,
+                                                             int B, int H, int lq_pad, int lk_pad, int long_q, int long_k,
+                                                             int grid, int* __restrict__ items, int* __restrict__ count) {
+    __shared__ int first[kVarlenMaxBatch + 1];  // first[r]: index of the r-th sequence's first entry
+    __shared__ int len_q[kVarlenMaxBatch], len_k[kVarlenMaxBatch];  // valid lengths; len_k = 0: not the tuned kernel's
+    __shared__ unsigned short order[kVarlenMaxBatch];               // order[r]: which sequence comes r-th
+    __shared__ int scan[256];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        carry = 0;
+        first[0] = 0;
+    }
+    for (int b = tid; b < B; b += 256) {
+        const int ql = q_len ? min(max(q_len[b], 0), lq_pad) : lq_pad;
+        const int kl = k_len ? min(max(k_len[b], 0), lk_pad) : lk_pad;
+        len_q[b] = ql;
+        len_k[b] = ql >= long_q && kl >= long_k ? kl : 0;
+    }
+    __syncthreads();
+    if (B <= kVarlenSortMax) {
+        for (int b = tid; b < B; b += 256) {  // rank by counting: costlier sequences first, equal ones by index
+            const int c = len_k[b];
+            int rank = 0;
+            for (int j = 0; j < B; ++j) rank += len_k[j] > c || (len_k[j] == c && j < b);
+            order[rank] = (unsigned short)b;
+        }
+    } else {
+        for (int b = tid; b < B; b += 256) order[b] = (unsigned short)b;
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < B; r0 += 256) {  // inclusive scan of the sequences' item counts, 256 at a time
+        const int r = r0 + tid;
+        int n = 0;
+        if (r < B && len_k[order[r]] > 0) n = H * ((len_q[order[r]] + 255) / 256);
+        scan[tid] = n;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = tid >= d ? scan[tid - d] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        if (r < B) first[r + 1] = carry + scan[tid];
+        __syncthreads();
+        if (tid == 255) carry += scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) *count = carry;
+    const int total = carry;
+    const int last_round = (total - 1) / grid;
+    for (int i = tid; i < total; i += 256) {
+        int lo = 0, hi = B - 1;  // the rank r with first[r] <= i < first[r + 1]
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (first[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int b = order[lo];
+        const int ql = len_q[b], kl = len_k[b];
+        const int nblk = (ql + 255) / 256, j = i - first[lo];
+        // groups of eight heads (the last one smaller), a group's blocks interleaved
+        const int per_group = 8 * nblk, grp = j / per_group;
+        const int gh = min(8, H - 8 * grp), r = j - grp * per_group;
+        const int blk = r / gh, hd = 8 * grp + (r - blk * gh);
+        const int round = i / grid, pos = i - round * grid;
+        const int dest = (last_round - round) & 1 ? round * grid + (grid - 1 - pos) : i;
+        int* e = items + 4 * (size_t)dest;
+        e[0] = b * H + hd;
+        e[1] = blk;
+        e[2] = ql;
+        e[3] = kl;
+    }
+}
+
 // Whole tiles, no mask, every head's keys split into ranges (see SPLIT above).
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_split_kernel(const FwdParams p) {
     fa_fwd_w64_body<false, false, true>(p);
@@ -1326,6 +1472,9 @@ __global__ __launch_bounds__(256) void fa_split_merge_kernel(const float* __rest
 }
 
 #undef W64_STAMP
+#undef W64_LQ_C
+#undef W64_LQ_N
+#undef W64_LK_C
 #undef W64_ADVANCE
 #undef W64_DMA_K
 #undef W64_DMA_V

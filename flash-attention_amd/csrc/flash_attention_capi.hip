@@ -63,6 +63,7 @@ struct Switches {
     bool block_tuned = true;
     int split = -1;  // -1: the cost model's choice
     bool hd = true, hd_masked = true;
+    bool varlen_w64 = true;
 };
 std::atomic<const Switches*> g_switches{nullptr};
 std::once_flag g_switches_once;
@@ -86,6 +87,7 @@ const Switches* read_switches() {
     if (geti("FA_BLOCK_TUNED", x)) sw->block_tuned = x != 0;
     if (geti("FA_SPLIT", x) && x >= 0) sw->split = x;
     if (geti("FA_HD", x)) sw->hd = x != 0, sw->hd_masked = x != 1;
+    if (geti("FA_VARLEN_W64", x)) sw->varlen_w64 = x != 0;
     if (geti("FA_RESERVED_CUS", x) && x >= 0) g_reserved_cus.store(x, std::memory_order_relaxed);
     return sw;
 }
@@ -606,6 +608,54 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
     return FA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Padded batches at D = 128 without mask: sequences of at least kVarlenLongRows query rows and keys run on the
+// tuned kernel's ragged form (fa_fwd_w64_varlen_kernel, items with their own lengths from a list that
+// fa_varlen_plan_kernel builds on the device, where the lengths are), the batch's other sequences on the 128-row
+// kernel, which leaves the long ones alone; both launches cover the whole batch and sort the sequences out
+// themselves.  The threshold is where the ragged tuned form overtakes the 128-row kernel on single sequences
+// (masked_on_w64: 1100).  Only when the padded lengths admit a long sequence at all; not on a capturing stream
+// (the list comes from the stream's pool); FA_VARLEN_W64=0 or FA_MASKED_W64=0 keeps everything on the 128-row
+// kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int kVarlenLongRows = 1100;
+bool varlen_on_w64(int B, int Lq, int Lk, int D, int flags, hipStream_t stream) {
+    const Switches& sw = switches();
+    if (D != fa::kHeadDim || flags != 0 || Lq < kVarlenLongRows || Lk < kVarlenLongRows) return false;
+    if (B > fa::kVarlenMaxBatch || !sw.varlen_w64 || sw.masked_w64 == 0 || !sw.persistent) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    return true;
+}
+int launch_varlen_long_and_short(const fa::FwdParams& base, int B, int H, hipStream_t stream) {
+    const long max_items = (long)base.bh * ((base.lq + 255) / 256);
+    const size_t bytes = (size_t)max_items * 4 * sizeof(int) + 256;
+    void* ws = nullptr;
+    if (hipMallocAsync(&ws, bytes, stream) != hipSuccess || !ws) {
+        (void)hipGetLastError();  // no stream-ordered allocator: the 128-row kernel takes the whole batch
+        return launch_hd_maybe_split(base, fa::kHeadDim, kHdMasked, stream);
+    }
+    fa::FwdParams p = base;
+    int* count = static_cast<int*>(ws);
+    int* items = count + 64;  // (256-byte aligned behind the count)
+    p.varlen_count = count;
+    p.varlen_items = items;
+    p.long_q = p.long_k = kVarlenLongRows;
+    p.q_blocks = (p.lq + 255) / 256;
+    p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
+    long grid = persistent_grid();
+    if (grid > max_items) grid = max_items;
+    hipLaunchKernelGGL(fa::fa_varlen_plan_kernel, dim3(1), dim3(256), 0, stream, base.q_len, base.k_len, B, H, base.lq,
+                       base.lk, p.long_q, p.long_k, (int)grid, items, count);
+    hipLaunchKernelGGL(fa::fa_fwd_w64_varlen_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    int rc = hipGetLastError() == hipSuccess ? FA_OK : fail(FA_ERR_RUNTIME, "fa_forward_varlen: launch failed%s");
+    // the other sequences (and every sequence's rows stay untouched behind its length); no key split here: its
+    // merge would also fold the sequences this kernel leaves alone
+    if (rc == FA_OK) rc = launch_hd_any(p, fa::kHeadDim, kHdMasked, stream);
+    (void)hipFreeAsync(ws, stream);
+    return rc;
+}
+
 // Which kernel folds one block in fa_forward_block_general.  A block that needs no mask (no flag, or every key of
 // it at or before the first query row) goes to the tuned kernels: the unmasked ones in whole tiles, the
 // ragged form otherwise (where masked_on_w64() picks it); the diagonal block of a causal sequence (same
@@ -855,8 +905,11 @@ int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV
     p.q_len = d_q_len;
     p.k_len = d_k_len;
     p.heads_per_batch = H;
-    if (switches().hd && switches().hd_masked)
+    if (switches().hd && switches().hd_masked) {
+        if (varlen_on_w64(B, Lq, Lk, D, flags, stream))
+            return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_varlen_long_and_short(p, B, H, stream); });
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_maybe_split(p, D, kHdMasked, stream); });
+    }
     return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_general(p, D, stream); });
 }
 

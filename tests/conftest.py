@@ -27,7 +27,7 @@ def fa():
 
 
 SWITCHES = ("FA_W64", "FA_PERSISTENT", "FA_MASKED_W64", "FA_BLOCK_TUNED", "FA_SPLIT", "FA_RESERVED_CUS", "FA_NWAVES",
-            "FA_RING", "FA_HD")
+            "FA_RING", "FA_HD", "FA_VARLEN_W64")
 
 
 @pytest.fixture

@@ -52,16 +52,21 @@ def within_gate(ref, out16):
 for it in range(args.iters if args.varlen else 0):
     D = int(rng.choice([64, 128, 256]))
     B, H = int(rng.integers(1, 7)), int(rng.integers(1, 4))
-    kind = ("self", "cross", "decode")[it % 3]
-    causal = bool(rng.integers(0, 2)) and kind != "decode"
-    if kind == "self":
+    kind = ("self", "cross", "decode", "long")[it % 4]
+    causal = bool(rng.integers(0, 2)) and kind not in ("decode", "long")
+    if kind == "long":  # D = 128, lengths on both sides of 1100: the tuned kernel's per-item lengths beside the 128-row kernel
+        D, H = 128, int(rng.choice([1, 2, 3, 8, 9, 10]))
+        B = int(rng.integers(1, max(2, 14 // H + 1)))
+        Lq, Lk = int(rng.integers(1100, 2200)), int(rng.integers(1100, 2600))
+    elif kind == "self":
         Lq = Lk = int(rng.integers(1, 700))
     elif kind == "cross":
         Lq, Lk = int(rng.integers(1, 500)), int(rng.integers(1, 700))
     else:
         Lq, Lk = int(rng.integers(1, 17)), int(rng.integers(1000, 8000))
-    q_lens = [int(rng.integers(0, Lq + 1)) if rng.integers(0, 4) else Lq for _ in range(B)]
-    k_lens = [int(rng.integers(0, Lk + 1)) if rng.integers(0, 4) else Lk for _ in range(B)]
+    low = 900 if kind == "long" else 0
+    q_lens = [int(rng.integers(low, Lq + 1)) if rng.integers(0, 4) else Lq for _ in range(B)]
+    k_lens = [int(rng.integers(low, Lk + 1)) if rng.integers(0, 4) else Lk for _ in range(B)]
     if kind == "self":
         k_lens = list(q_lens)
     scale = float(rng.uniform(0.3, 1.6))

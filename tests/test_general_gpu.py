@@ -597,6 +597,59 @@ def test_padded_batch_only_key_lengths_given(fa, oracle, dev):
     assert torch.equal(o2, fa.attention_general(q, k, v))
 
 
+@pytest.mark.parametrize("H", [9, 2])
+def test_padded_batch_long_and_short_sequences(fa, oracle, dev, H, fa_env):
+    """A padded batch at D = 128 whose lengths straddle the threshold (1100 query rows and keys) from which a
+    sequence runs on the tuned kernel's ragged form with its own lengths: both sides of it by one row, lengths that
+    are and are not whole tiles, a sequence long in rows and short in keys (and the other way round), an empty
+    one, and 9 heads (groups of eight and one) / 2.  The two kernels write disjoint sequences; together the
+    batch; same bits as the 128-row kernel alone on the short sequences."""
+    import torch
+
+    q_lens = [1400, 1100, 1099, 1250, 0, 1400, 300, 1153]
+    k_lens = [1400, 1234, 1400, 1100, 700, 1099, 1400, 1153]
+    if H == 2:  # longer sequences, different padded lengths
+        q_lens, k_lens = [2600, 1101, 64, 2305], [1100, 3000, 3000, 2111]
+    B = len(q_lens)
+    fa_env(FA_VARLEN_W64=None)
+    _varlen_case(fa, oracle, dev, B, H, max(q_lens), max(k_lens), 128, q_lens, k_lens, False, seed=4100 + H)
+    # against the 128-row kernel alone: the short sequences' bits are the same, the long ones agree to the gate
+    rng = np.random.default_rng(4200 + H)
+    Q, K, V = [torch.from_numpy(rng.standard_normal((B, H, n, 128), dtype=np.float32).astype(np.float16)).to(dev)
+               for n in (max(q_lens), max(k_lens), max(k_lens))]
+    ql = torch.tensor(q_lens, dtype=torch.int32, device=dev)
+    kl = torch.tensor(k_lens, dtype=torch.int32, device=dev)
+    both = fa.attention_varlen(Q, K, V, ql, kl)
+    fa_env(FA_VARLEN_W64="0")
+    one = fa.attention_varlen(Q, K, V, ql, kl)
+    fa_env(FA_VARLEN_W64=None)
+    torch.cuda.synchronize()
+    for b in range(B):
+        if q_lens[b] < 1100 or k_lens[b] < 1100:
+            assert torch.equal(both[b], one[b]), f"sequence {b}"
+        else:
+            d = (both[b, :, :q_lens[b]].float() - one[b, :, :q_lens[b]].float()).abs().max().item()
+            assert d <= 2e-3, f"sequence {b}: {d}"
+
+
+def test_padded_batch_long_sequences_without_query_lengths(fa, oracle, dev):
+    """k_len alone on long padded lengths: every query row of the padded tensor against its sequence's keys
+    (sequences with at least 1100 keys on the tuned kernel, the others on the 128-row kernel)."""
+    import torch
+
+    B, H, L, D = 3, 2, 1300, 128
+    Q, K, V = normal_fp16(56, (B, H, L, D))
+    k_lens = [1300, 1100, 37]
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    o = fa.attention_varlen(q, k, v, None, torch.tensor(k_lens, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    for b in range(B):
+        st = oracle.BlockState(1, H, L, D)
+        oracle.block_update(st, np.ascontiguousarray(Q[b:b + 1]), np.ascontiguousarray(K[b:b + 1, :, :k_lens[b]]),
+                            np.ascontiguousarray(V[b:b + 1, :, :k_lens[b]]))
+        gate(oracle, oracle.block_finalize(st), o[b:b + 1].cpu().numpy(), f"sequence {b}")
+
+
 @pytest.mark.parametrize("Lq,Lk", [(200, 328), (320, 192)])
 def test_causal_mask_with_different_lengths_and_no_length_arrays(fa, oracle, dev, Lq, Lk):
     """fa_forward_varlen under the causal mask with Lq != Lk: accepted with both length arrays NULL exactly as with

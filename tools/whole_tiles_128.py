@@ -4,6 +4,7 @@ fa_forward_varlen with every k_len = L), B*L = 16384 rows, H = 16, pattern data.
 
     python tools/whole_tiles_128.py [L | LqxLk ...]"""
 import os, sys, time
+os.environ["FA_VARLEN_W64"] = "0"  # (padded batches stay on the 128-row kernel: that is the comparison)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
