@@ -375,8 +375,9 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         if constexpr (STATE)
             if (p.k_splits > 1) lk_v = min(max(lk_v - key_first, 0), p.lk_split);
         if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
-        // (a padded batch whose long sequences run on fa_fwd_w64_varlen_kernel, launched beside this one)
-        if (p.long_q > 0 && lq_v >= p.long_q && lk_v >= p.long_k) return;
+        // (a padded batch whose long sequences run on the fa_fwd_w64_varlen kernels, launched before this one: the list's
+        // planner left this launch's thresholds behind the item count)
+        if (p.long_q > 0 && varlen_on_tuned(lq_v, lk_v, p.varlen_count[1], p.varlen_count[2], causal)) return;
     }
     const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
     const bool wave_valid = q_row0 < lq_v;              // a wave past the last row computes along and stores nothing

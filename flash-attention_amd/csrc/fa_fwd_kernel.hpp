@@ -63,6 +63,16 @@ enum : int {
     kFlagCausal = 4,      // key k_pos0 + j > query q_pos0 + i is masked (the kernels that know the mask)
 };
 
+// Padded batches at D = 128: which sequences run on the tuned kernel's list form (fa_fwd_w64_varlen kernels) and which on the
+// 128-row kernel launched beside it; both kernels and the list's planner ask this.  Without the mask: at least
+// long_q query rows and long_k keys.  With it: the same count of rows and keys (the tuned kernels' mask assumes
+// it), and at least long_q of them when the last 256-row block holds more than 128 rows, long_k otherwise (a last
+// block that is mostly idle weighs more on the 256-row items).
+__host__ __device__ inline bool varlen_on_tuned(int ql, int kl, int long_q, int long_k, bool causal) {
+    if (!causal) return ql >= long_q && kl >= long_k;
+    return ql == kl && ql >= (((ql - 1) & 255) + 1 > 128 ? long_q : long_k);
+}
+
 struct FwdParams {
     const half_t* q;  // [bh][lq][128]
     const half_t* k;  // [bh][lk][128]

@@ -684,7 +684,7 @@ __device__ __forceinline__ void mask_scores(f32x16& s0, f32x16& s1, int thr, int
 //     four steps that carry them run 150 - 250 cycles longer and every other step 80: +1 % at L = 448 and 512,
 //     nothing at 640 - 1024, -1 ... 2 % from 1280 on.  Not instantiated in the library; -DW64_QSTREAM_DEFAULT=true
 //     builds the plain kernel in this form (tools/build_w64_only.sh).
-//   VARLEN (with RAGGED, no mask) takes its items from a list in device memory instead of numbering them: entry i =
+//   VARLEN (with RAGGED, with or without CAUSAL) takes its items from a list in device memory instead of numbering them: entry i =
 //     (head, 256-row block, query rows, keys) of a padded batch's sequence, so that every item has its own lengths
 //     (tile count, shifted last tile, last query rows) while the strides stay the padded ones; *p.varlen_count
 //     items.  For the long sequences of fa_forward_varlen's batches; the list is built on the device by
@@ -693,7 +693,7 @@ template <bool CAUSAL, bool RAGGED, bool SPLIT = false, bool QSTREAM = false, bo
 __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     static_assert(!SPLIT || (!CAUSAL && !RAGGED), "the key split is built for whole tiles without a mask");
     static_assert(!QSTREAM || (!CAUSAL && !RAGGED && !SPLIT), "Q streaming is built for the plain form");
-    static_assert(!VARLEN || (RAGGED && !CAUSAL && !SPLIT && !QSTREAM), "per-item lengths are built on the ragged form");
+    static_assert(!VARLEN || (RAGGED && !SPLIT && !QSTREAM), "per-item lengths are built on the ragged forms");
     constexpr bool MASKED = CAUSAL || RAGGED;
     constexpr int NWAVES = 4;
     constexpr int QB = 256;                        // query rows per item
@@ -747,6 +747,13 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         blk = e[1];
         lq_ = e[2];
         lk_ = e[3];
+    };
+    // tiles of a list item and the rows its last tile repeats: all of the sequence's tiles, the last one shifted to
+    // end at the last key; with the mask only those up to the block's diagonal, and no shift unless they reach the end
+    [[maybe_unused]] auto item_shape = [&](int blk, int lk_, int& nt_, int& dup_) {
+        const int full = (lk_ + kKvTile - 1) / kKvTile;
+        nt_ = CAUSAL && 4 * (blk + 1) < full ? 4 * (blk + 1) : full;
+        dup_ = nt_ == full ? full * kKvTile - lk_ : 0;
     };
 #define W64_LQ_C (VARLEN ? lq_c : p.lq)
 #define W64_LQ_N (VARLEN ? nlq : p.lq)
@@ -822,8 +829,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             if (VARLEN) {                                                                      \
                 int lq_, lk_;                                                                  \
                 list_item((cur_).item, (cur_).head, (cur_).qb, lq_, lk_);                      \
-                (cur_).nt = (lk_ + kKvTile - 1) / kKvTile;                                     \
-                (cur_).dup = (cur_).nt * kKvTile - lk_;                                        \
+                item_shape((cur_).qb, lk_, (cur_).nt, (cur_).dup);                             \
                 (cur_).off = kv_base((cur_).head);                                             \
             } else if (!CAUSAL && inc_wrap != 0) {                                             \
                 (cur_).qb += inc_qb;                                                           \
@@ -870,9 +876,8 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
     } else {
         decode(item, head, qb);
     }
-    std::conditional_t<CAUSAL || VARLEN, int, const int> n_tiles =
-        VARLEN ? (lk_c + kKvTile - 1) / kKvTile : item_tiles(qb);  // of the item being computed
-    if constexpr (VARLEN) dup = n_tiles * kKvTile - lk_c;
+    std::conditional_t<CAUSAL || VARLEN, int, const int> n_tiles = item_tiles(qb);  // of the item being computed
+    if constexpr (VARLEN) item_shape(qb, lk_c, n_tiles, dup);
     // A wave's 64 rows of a query block, or, when the block is the sequence's last and ends before them
     // (lq is a multiple of 64, not necessarily of 256), the block's first 64 rows as a stand-in source:
     // such a wave computes along (it moves its share of every tile and meets every barrier) and stores
@@ -1310,12 +1315,12 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
             head = nhead;
             qb = nqb;
             wrow = nwrow;
-            if constexpr (CAUSAL) n_tiles = item_tiles(qb);
             if constexpr (VARLEN) {
                 lq_c = nlq;
                 lk_c = nlk;
-                n_tiles = (lk_c + kKvTile - 1) / kKvTile;
-                dup = n_tiles * kKvTile - lk_c;
+                item_shape(qb, lk_c, n_tiles, dup);
+            } else if constexpr (CAUSAL) {
+                n_tiles = item_tiles(qb);
             }
             if constexpr (MASKED) lim = row_pos(qb, W64_LQ_C);
             t = -1;
@@ -1345,43 +1350,85 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_kernel(const FwdPara
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_ragged_causal_kernel(const FwdParams p) {
     fa_fwd_w64_body<true, true>(p);
 }
-// The ragged form over a device-built list of items with their own lengths (see VARLEN above).
+// The ragged forms over a device-built list of items with their own lengths (see VARLEN above).
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_varlen_kernel(const FwdParams p) {
     fa_fwd_w64_body<false, true, false, false, true>(p);
 }
-// The item list of fa_fwd_w64_varlen_kernel, built where the lengths live.  One workgroup: per sequence the valid
-// lengths (clamped to the padded ones; a null array means the padded length), whether the tuned kernel takes the
-// sequence (at least long_q query rows and long_k keys) and its number of items H * ceil(q / 256); the sequences
-// in descending order of keys (an item's cost; batches of up to kVarlenSortMax sequences, larger ones keep their
-// order); a scan over them; then every thread writes its share of the entries (head, block, query rows, keys).
-// Within a sequence the heads go in groups of eight with the group's blocks interleaved (block 0 of heads 0-7,
-// block 1 of heads 0-7, ...): with H a multiple of 8 an entry's index is then congruent to its head mod 8,
-// workgroup ids congruent mod 8 share an XCD, and a head's K/V stay in one L2, as in decode_item.
-// Workgroup w of `grid` takes entries w, w + grid, ...: the entries are laid down in rounds of `grid`, every other
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_varlen_causal_kernel(const FwdParams p) {
+    fa_fwd_w64_body<true, true, false, false, true>(p);
+}
+// The item list of the fa_fwd_w64_varlen kernels, built where the lengths live.  One workgroup: per sequence the
+// valid lengths (clamped to the padded ones; a null array means the padded length) and whether the tuned kernel
+// takes the sequence (varlen_on_tuned); the sequences in descending order of keys (batches of up to kVarlenSortMax
+// sequences, larger ones keep their order); a scan over groups of entries; then every thread writes its share of
+// the entries (head, block, query rows, keys).
+//   Without the mask an item costs its sequence's keys, and a group is a sequence: H * ceil(q / 256) entries, the
+// heads in groups of eight with the group's blocks interleaved (block 0 of heads 0-7, block 1 of heads 0-7, ...):
+// with H a multiple of 8 an entry's index is then congruent to its head mod 8, workgroup ids congruent mod 8 share
+// an XCD, and a head's K/V stay in one L2, as in decode_item.
+//   With the mask an item costs its block's diagonal, 4 (block + 1) tiles, and a group is a block index, the
+// highest first (decode_item_causal's order): the sequences that have that block are a prefix of the sorted order,
+// H entries each.  (This order needs the sort: the launcher keeps larger masked batches off this kernel.)
+//   Workgroup w of `grid` takes entries w, w + grid, ...: the entries are laid down in rounds of `grid`, every other
 // round back to front (the last one forwards, so that it has no holes), which hands the workgroup with the
 // costliest item of one round the cheapest of the next.  With a few items per workgroup whose costs differ by a
 // factor of three, the busiest workgroup then carries 7 - 10 % more than the mean instead of 15 - 18 %.
 constexpr int kVarlenMaxBatch = 4096;
 constexpr int kVarlenSortMax = 512;
+constexpr int kVarlenMaxBlocks = 4096;  // (with the mask: block indices are groups)
 __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restrict__ q_len, const int* __restrict__ k_len,
                                                              int B, int H, int lq_pad, int lk_pad, int long_q, int long_k,
-                                                             int grid, int* __restrict__ items, int* __restrict__ count) {
-    __shared__ int first[kVarlenMaxBatch + 1];  // first[r]: index of the r-th sequence's first entry
+                                                             int causal, int grid, int* __restrict__ items,
+                                                             int* __restrict__ count) {
+    __shared__ int first[kVarlenMaxBatch + 1];  // first[g]: index of group g's first entry
     __shared__ int len_q[kVarlenMaxBatch], len_k[kVarlenMaxBatch];  // valid lengths; len_k = 0: not the tuned kernel's
     __shared__ unsigned short order[kVarlenMaxBatch];               // order[r]: which sequence comes r-th
     __shared__ int scan[256];
+    __shared__ float wsum[2][256];
     __shared__ int carry;
     const int tid = threadIdx.x;
     if (tid == 0) {
         carry = 0;
         first[0] = 0;
     }
+    // The thresholds of this launch.  The two kernels run one after the other, and a handful of sequences below the
+    // thresholds makes the second one a launch of a few workgroups whose longest sets its time; when the
+    // sequences below them that the list form can take at all (64 rows and 192 keys; with the mask as many rows as
+    // keys) hold at most a quarter of the batch's work, they join the list instead and the thresholds drop to
+    // that minimum.  count[1], count[2] carry them to the 128-row kernel.
+    float w_long = 0.0f, w_mid = 0.0f;
+    const int min_q = causal ? 3 * kKvTile : kKvTile, min_k = 3 * kKvTile;
     for (int b = tid; b < B; b += 256) {
         const int ql = q_len ? min(max(q_len[b], 0), lq_pad) : lq_pad;
         const int kl = k_len ? min(max(k_len[b], 0), lk_pad) : lk_pad;
         len_q[b] = ql;
-        len_k[b] = ql >= long_q && kl >= long_k ? kl : 0;
+        len_k[b] = kl;
+        const float w = (float)ql * (float)kl;
+        if (varlen_on_tuned(ql, kl, long_q, long_k, causal != 0))
+            w_long += w;
+        else if (varlen_on_tuned(ql, kl, min_q, min_k, causal != 0))
+            w_mid += w;
     }
+    wsum[0][tid] = w_long;
+    wsum[1][tid] = w_mid;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) {
+            wsum[0][tid] += wsum[0][tid + d];
+            wsum[1][tid] += wsum[1][tid + d];
+        }
+        __syncthreads();
+    }
+    if (wsum[0][0] > 0.0f && wsum[1][0] <= 0.25f * (wsum[0][0] + wsum[1][0])) {
+        long_q = min_q;
+        long_k = min_k;
+    }
+    if (tid == 0) {
+        count[1] = long_q;
+        count[2] = long_k;
+    }
+    for (int b = tid; b < B; b += 256)
+        if (!varlen_on_tuned(len_q[b], len_k[b], long_q, long_k, causal != 0)) len_k[b] = 0;
     __syncthreads();
     if (B <= kVarlenSortMax) {
         for (int b = tid; b < B; b += 256) {  // rank by counting: costlier sequences first, equal ones by index
@@ -1394,10 +1441,26 @@ __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restri
         for (int b = tid; b < B; b += 256) order[b] = (unsigned short)b;
     }
     __syncthreads();
-    for (int r0 = 0; r0 < B; r0 += 256) {  // inclusive scan of the sequences' item counts, 256 at a time
-        const int r = r0 + tid;
+    // blocks of the r-th sequence (0: not the tuned kernel's)
+    auto blocks_of = [&](int r) { return len_k[order[r]] > 0 ? (len_q[order[r]] + 255) / 256 : 0; };
+    const int top = causal ? blocks_of(0) : 0;  // masked: groups are block indices top - 1 ... 0
+    const int groups = causal ? top : B;
+    for (int g0 = 0; g0 < groups; g0 += 256) {  // inclusive scan of the groups' entry counts, 256 at a time
+        const int g = g0 + tid;
         int n = 0;
-        if (r < B && len_k[order[r]] > 0) n = H * ((len_q[order[r]] + 255) / 256);
+        if (g < groups) {
+            if (causal) {  // sequences with more than `blk` blocks: a prefix of the (descending) order
+                const int blk = top - 1 - g;
+                int lo = 0, hi = B;  // first r with blocks_of(r) <= blk
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (blocks_of(mid) > blk) lo = mid + 1; else hi = mid;
+                }
+                n = H * lo;
+            } else {
+                n = H * blocks_of(g);
+            }
+        }
         scan[tid] = n;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) {
@@ -1406,7 +1469,7 @@ __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restri
             scan[tid] += v;
             __syncthreads();
         }
-        if (r < B) first[r + 1] = carry + scan[tid];
+        if (g < groups) first[g + 1] = carry + scan[tid];
         __syncthreads();
         if (tid == 255) carry += scan[255];
         __syncthreads();
@@ -1415,25 +1478,34 @@ __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restri
     const int total = carry;
     const int last_round = (total - 1) / grid;
     for (int i = tid; i < total; i += 256) {
-        int lo = 0, hi = B - 1;  // the rank r with first[r] <= i < first[r + 1]
+        int lo = 0, hi = groups - 1;  // the group g with first[g] <= i < first[g + 1]
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (first[mid] <= i) lo = mid; else hi = mid - 1;
         }
-        const int b = order[lo];
-        const int ql = len_q[b], kl = len_k[b];
-        const int nblk = (ql + 255) / 256, j = i - first[lo];
-        // groups of eight heads (the last one smaller), a group's blocks interleaved
-        const int per_group = 8 * nblk, grp = j / per_group;
-        const int gh = min(8, H - 8 * grp), r = j - grp * per_group;
-        const int blk = r / gh, hd = 8 * grp + (r - blk * gh);
+        const int j = i - first[lo];
+        int b, blk, hd;
+        if (causal) {
+            const int r = j / H;
+            b = order[r];
+            hd = j - r * H;
+            blk = top - 1 - lo;
+        } else {
+            b = order[lo];
+            const int nblk = (len_q[b] + 255) / 256;
+            // groups of eight heads (the last one smaller), a group's blocks interleaved
+            const int per_group = 8 * nblk, grp = j / per_group;
+            const int gh = min(8, H - 8 * grp), r = j - grp * per_group;
+            blk = r / gh;
+            hd = 8 * grp + (r - blk * gh);
+        }
         const int round = i / grid, pos = i - round * grid;
         const int dest = (last_round - round) & 1 ? round * grid + (grid - 1 - pos) : i;
         int* e = items + 4 * (size_t)dest;
         e[0] = b * H + hd;
         e[1] = blk;
-        e[2] = ql;
-        e[3] = kl;
+        e[2] = len_q[b];
+        e[3] = len_k[b];
     }
 }
 

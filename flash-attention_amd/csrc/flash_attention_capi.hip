@@ -609,19 +609,26 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Padded batches at D = 128 without mask: sequences of at least kVarlenLongRows query rows and keys run on the
-// tuned kernel's ragged form (fa_fwd_w64_varlen_kernel, items with their own lengths from a list that
-// fa_varlen_plan_kernel builds on the device, where the lengths are), the batch's other sequences on the 128-row
-// kernel, which leaves the long ones alone; both launches cover the whole batch and sort the sequences out
-// themselves.  The threshold is where the ragged tuned form overtakes the 128-row kernel on single sequences
-// (masked_on_w64: 1100).  Only when the padded lengths admit a long sequence at all; not on a capturing stream
-// (the list comes from the stream's pool); FA_VARLEN_W64=0 or FA_MASKED_W64=0 keeps everything on the 128-row
-// kernel.
+// Padded batches at D = 128: the long sequences run on the tuned kernel's ragged forms (fa_fwd_w64_varlen_kernel,
+// fa_fwd_w64_varlen_causal_kernel: items with their own lengths from a list that fa_varlen_plan_kernel builds on the
+// device, where the lengths are), the batch's other sequences on the 128-row kernel, which leaves the long ones
+// alone; both launches cover the whole batch and sort the sequences out themselves (fa::varlen_on_tuned).  The
+// thresholds are where the ragged tuned forms overtake the 128-row kernel on single sequences (masked_on_w64):
+// without the mask 1100 query rows and keys; with it 1665 rows = keys when the last 256-row block is more than
+// half full, else 2305.  Only when the padded lengths admit a long sequence at all; not on a capturing stream (the
+// list comes from the stream's pool); with the mask only batches the planner sorts (its item order needs that) and
+// equal padded lengths; FA_VARLEN_W64=0 or FA_MASKED_W64=0 keeps everything on the 128-row kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int kVarlenLongRows = 1100;
+constexpr int kVarlenLongRows = 1100, kVarlenLongCausalFull = 1665, kVarlenLongCausal = 2305;
 bool varlen_on_w64(int B, int Lq, int Lk, int D, int flags, hipStream_t stream) {
     const Switches& sw = switches();
-    if (D != fa::kHeadDim || flags != 0 || Lq < kVarlenLongRows || Lk < kVarlenLongRows) return false;
+    if (D != fa::kHeadDim || (flags & ~FA_FLAG_CAUSAL)) return false;
+    if (flags & FA_FLAG_CAUSAL) {
+        if (Lq != Lk || Lq < kVarlenLongCausalFull || B > fa::kVarlenSortMax) return false;
+        if ((Lq + 255) / 256 > fa::kVarlenMaxBlocks) return false;
+    } else if (Lq < kVarlenLongRows || Lk < kVarlenLongRows) {
+        return false;
+    }
     if (B > fa::kVarlenMaxBatch || !sw.varlen_w64 || sw.masked_w64 == 0 || !sw.persistent) return false;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
@@ -631,23 +638,28 @@ int launch_varlen_long_and_short(const fa::FwdParams& base, int B, int H, hipStr
     const long max_items = (long)base.bh * ((base.lq + 255) / 256);
     const size_t bytes = (size_t)max_items * 4 * sizeof(int) + 256;
     void* ws = nullptr;
-    if (hipMallocAsync(&ws, bytes, stream) != hipSuccess || !ws) {
+    if (max_items > 0x7fffffffL || hipMallocAsync(&ws, bytes, stream) != hipSuccess || !ws) {
         (void)hipGetLastError();  // no stream-ordered allocator: the 128-row kernel takes the whole batch
         return launch_hd_maybe_split(base, fa::kHeadDim, kHdMasked, stream);
     }
+    const bool causal = (base.flags & fa::kFlagCausal) != 0;
     fa::FwdParams p = base;
     int* count = static_cast<int*>(ws);
     int* items = count + 64;  // (256-byte aligned behind the count)
     p.varlen_count = count;
     p.varlen_items = items;
-    p.long_q = p.long_k = kVarlenLongRows;
+    p.long_q = causal ? kVarlenLongCausalFull : kVarlenLongRows;
+    p.long_k = causal ? kVarlenLongCausal : kVarlenLongRows;
     p.q_blocks = (p.lq + 255) / 256;
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
     long grid = persistent_grid();
     if (grid > max_items) grid = max_items;
     hipLaunchKernelGGL(fa::fa_varlen_plan_kernel, dim3(1), dim3(256), 0, stream, base.q_len, base.k_len, B, H, base.lq,
-                       base.lk, p.long_q, p.long_k, (int)grid, items, count);
-    hipLaunchKernelGGL(fa::fa_fwd_w64_varlen_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+                       base.lk, p.long_q, p.long_k, causal ? 1 : 0, (int)grid, items, count);
+    if (causal)
+        hipLaunchKernelGGL(fa::fa_fwd_w64_varlen_causal_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(fa::fa_fwd_w64_varlen_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     int rc = hipGetLastError() == hipSuccess ? FA_OK : fail(FA_ERR_RUNTIME, "fa_forward_varlen: launch failed%s");
     // the other sequences (and every sequence's rows stay untouched behind its length); no key split here: its
     // merge would also fold the sequences this kernel leaves alone

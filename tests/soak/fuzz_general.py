@@ -58,6 +58,9 @@ for it in range(args.iters if args.varlen else 0):
         D, H = 128, int(rng.choice([1, 2, 3, 8, 9, 10]))
         B = int(rng.integers(1, max(2, 14 // H + 1)))
         Lq, Lk = int(rng.integers(1100, 2200)), int(rng.integers(1100, 2600))
+        if it % 8 == 3:  # with the mask: as many rows as keys, thresholds 1665 / 2305
+            causal, Lq = True, int(rng.integers(1665, 2700))
+            Lk = Lq
     elif kind == "self":
         Lq = Lk = int(rng.integers(1, 700))
     elif kind == "cross":
@@ -67,8 +70,10 @@ for it in range(args.iters if args.varlen else 0):
     low = 900 if kind == "long" else 0
     q_lens = [int(rng.integers(low, Lq + 1)) if rng.integers(0, 4) else Lq for _ in range(B)]
     k_lens = [int(rng.integers(low, Lk + 1)) if rng.integers(0, 4) else Lk for _ in range(B)]
-    if kind == "self":
+    if kind == "self" or (kind == "long" and causal):
         k_lens = list(q_lens)
+        if kind == "long" and B > 1:  # one sequence whose rows and keys differ: never the tuned kernel's
+            k_lens[0] = max(1, q_lens[0] - int(rng.integers(1, 100)))
     scale = float(rng.uniform(0.3, 1.6))
     Q = (rng.standard_normal((B, H, Lq, D), dtype=np.float32) * scale).astype(np.float16)
     K = (rng.standard_normal((B, H, Lk, D), dtype=np.float32) * scale).astype(np.float16)

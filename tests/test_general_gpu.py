@@ -597,13 +597,32 @@ def test_padded_batch_only_key_lengths_given(fa, oracle, dev):
     assert torch.equal(o2, fa.attention_general(q, k, v))
 
 
+def _on_tuned_kernel(q_lens, k_lens, causal):
+    """Which sequences of a padded D = 128 batch the library hands to the tuned kernel's list form (the rule of
+    fa_varlen_plan_kernel): those over the thresholds; and when the ones below them that the list form can take at
+    all hold at most a quarter of the batch's rows x keys, those as well."""
+    def over(ql, kl, tq, tk):
+        if not causal:
+            return ql >= tq and kl >= tk
+        return ql == kl and ql >= (tq if (ql - 1) % 256 + 1 > 128 else tk)
+
+    tq, tk = (1665, 2305) if causal else (1100, 1100)
+    mq, mk = (192, 192) if causal else (64, 192)
+    w_long = sum(float(a) * b for a, b in zip(q_lens, k_lens) if over(a, b, tq, tk))
+    w_mid = sum(float(a) * b for a, b in zip(q_lens, k_lens) if not over(a, b, tq, tk) and over(a, b, mq, mk))
+    if w_long > 0 and w_mid <= 0.25 * (w_long + w_mid):
+        tq, tk = mq, mk
+    return [over(a, b, tq, tk) for a, b in zip(q_lens, k_lens)]
+
+
 @pytest.mark.parametrize("H", [9, 2])
 def test_padded_batch_long_and_short_sequences(fa, oracle, dev, H, fa_env):
     """A padded batch at D = 128 whose lengths straddle the threshold (1100 query rows and keys) from which a
     sequence runs on the tuned kernel's ragged form with its own lengths: both sides of it by one row, lengths that
     are and are not whole tiles, a sequence long in rows and short in keys (and the other way round), an empty
     one, and 9 heads (groups of eight and one) / 2.  The two kernels write disjoint sequences; together the
-    batch; same bits as the 128-row kernel alone on the short sequences."""
+    batch; same bits as the 128-row kernel alone on the sequences it keeps.  In the 2-head batch the one short
+    sequence (64 rows) holds 2 % of the work and joins the list instead of costing a launch of its own."""
     import torch
 
     q_lens = [1400, 1100, 1099, 1250, 0, 1400, 300, 1153]
@@ -624,12 +643,51 @@ def test_padded_batch_long_and_short_sequences(fa, oracle, dev, H, fa_env):
     one = fa.attention_varlen(Q, K, V, ql, kl)
     fa_env(FA_VARLEN_W64=None)
     torch.cuda.synchronize()
+    tuned = _on_tuned_kernel(q_lens, k_lens, False)
+    assert tuned == ([True, True, False, True, False, False, False, True] if H == 9 else [True] * 4)
     for b in range(B):
-        if q_lens[b] < 1100 or k_lens[b] < 1100:
+        if not tuned[b]:
             assert torch.equal(both[b], one[b]), f"sequence {b}"
         else:
             d = (both[b, :, :q_lens[b]].float() - one[b, :, :q_lens[b]].float()).abs().max().item()
-            assert d <= 2e-3, f"sequence {b}: {d}"
+            assert 0 < d <= 2e-3, f"sequence {b}: {d}"  # (another kernel: some last bits differ)
+
+
+@pytest.mark.parametrize("H", [8, 3])
+def test_padded_batch_long_and_short_sequences_causal(fa, oracle, dev, H, fa_env):
+    """The same under the causal mask: a sequence runs on the tuned kernel's list form when it has as many rows as
+    keys and at least 1665 of them with a last 256-row block more than half full, 2305 otherwise; lengths on both
+    sides of each rule, an empty and a short sequence, and (second part) sequences whose rows and keys differ,
+    which stay on the 128-row kernel whatever their length."""
+    import torch
+
+    lens = [2305, 1665, 1664, 2100, 0, 2304, 700] if H == 3 else [1665, 2400, 1664, 1921]
+    B = len(lens)
+    fa_env(FA_VARLEN_W64=None)
+    _varlen_case(fa, oracle, dev, B, H, max(lens), max(lens), 128, lens, lens, True, seed=4300 + H)
+    rng = np.random.default_rng(4400 + H)
+    L = max(lens)
+    Q, K, V = [torch.from_numpy(rng.standard_normal((B, H, L, 128), dtype=np.float32).astype(np.float16)).to(dev)
+               for _ in range(3)]
+    k_lens = list(lens)
+    k_lens[0], k_lens[1] = lens[0] - 1, min(L, lens[1] + 300)  # rows != keys: not the tuned kernel's
+    ql = torch.tensor(lens, dtype=torch.int32, device=dev)
+    kl = torch.tensor(k_lens, dtype=torch.int32, device=dev)
+    both = fa.attention_varlen(Q, K, V, ql, kl, causal=True)
+    fa_env(FA_VARLEN_W64="0")
+    one = fa.attention_varlen(Q, K, V, ql, kl, causal=True)
+    fa_env(FA_VARLEN_W64=None)
+    torch.cuda.synchronize()
+    tuned_all = _on_tuned_kernel(lens, k_lens, True)
+    assert tuned_all == ([False, False, False, False, False, True, False] if H == 3 else [False, True, True, True])
+    for b in range(B):
+        n = lens[b]
+        tuned = tuned_all[b]
+        if not tuned:
+            assert torch.equal(both[b], one[b]), f"sequence {b}"
+        else:
+            d = (both[b, :, :n].float() - one[b, :, :n].float()).abs().max().item()
+            assert 0 < d <= 2e-3, f"sequence {b}: {d}"  # (another kernel: some last bits differ)
 
 
 def test_padded_batch_long_sequences_without_query_lengths(fa, oracle, dev):

@@ -4,7 +4,8 @@ kernel alone and next to one fa_forward_general call per sequence.
 
     python tools/bench_varlen.py [seed]
 
-Pattern data, 1 s of preheat per line, back-to-back launches between two events.  FLOPs: 4*H*D*sum(q_len*k_len).
+Pattern data, 1 s of preheat per line, back-to-back launches between two events.  FLOPs: 4*H*D*sum(q_len*k_len), with the causal mask
+the visible triangle 2*H*D*sum(n*(n+1)).
 Lines: lengths drawn uniformly from a range (padded to its upper end), then a batch with one long sequence among
 short ones, then all sequences at the padded length (what the two-kernel route costs when nothing is ragged)."""
 import os, sys, time
@@ -34,20 +35,21 @@ def timed(f, reps=20, preheat=1.0):
     return e0.elapsed_time(e1) / reps
 
 
-def case(label, lens, pad):
+def case(label, lens, pad, causal=False):
     B = len(lens)
     q, k, v, o = [torch.empty((B, H, pad, D), dtype=torch.float16, device=dev) for _ in range(4)]
     for t, seed in zip((q, k, v), (1234, 2345, 3456)):
         fa.init_half(t.view(-1), seed)
     ql = torch.tensor(lens, dtype=torch.int32, device=dev)
-    flops = 4.0 * H * D * sum(float(n) * n for n in lens)
+    flops = (2.0 * H * D * sum(float(n) * (n + 1) for n in lens) if causal else
+             4.0 * H * D * sum(float(n) * n for n in lens))
     out = []
     for name, env in (("two kernels", None), ("128-row kernel", "0")):
         os.environ.pop("FA_VARLEN_W64", None)
         if env is not None:
             os.environ["FA_VARLEN_W64"] = env
         fa.reload_env()
-        ms = timed(lambda: fa.attention_varlen(q, k, v, ql, ql, out=o))
+        ms = timed(lambda: fa.attention_varlen(q, k, v, ql, ql, causal=causal, out=o))
         out.append(f"{name} {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TFLOP/s")
     os.environ.pop("FA_VARLEN_W64", None)
     fa.reload_env()
@@ -55,10 +57,10 @@ def case(label, lens, pad):
 
     def per_sequence():
         for qs, ks, vs, os_ in seqs:
-            fa.attention_general(qs, ks, vs, out=os_)
+            fa.attention_general(qs, ks, vs, causal=causal, out=os_)
     ms = timed(per_sequence)
     out.append(f"one call per sequence {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TFLOP/s")
-    print(f"{label:34s} B={B:2d} pad={pad:5d} | " + " | ".join(out), flush=True)
+    print(f"{label + (', causal' if causal else ''):34s} B={B:2d} pad={pad:5d} | " + " | ".join(out), flush=True)
 
 
 case("uniform 1100..4096", [int(x) for x in rng.integers(1100, 4097, 8)], 4096)
@@ -69,3 +71,8 @@ case("one of 4096 among 15 of 200", [4096] + [200] * 15, 4096)
 case("all 2048 (nothing ragged)", [2048] * 8, 2048)
 case("all 2047", [2047] * 8, 2048)
 case("all 1024 (below the threshold)", [1024] * 16, 1024)
+case("uniform 1665..4096", [int(x) for x in rng.integers(1665, 4097, 8)], 4096, causal=True)
+case("uniform 2305..8192", [int(x) for x in rng.integers(2305, 8193, 4)], 8192, causal=True)
+case("uniform 64..4096", [int(x) for x in rng.integers(64, 4097, 8)], 4096, causal=True)
+case("all 4096", [4096] * 4, 4096, causal=True)
+case("all 4095", [4095] * 4, 4096, causal=True)

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "flash-attention_amd", "csrc", "flash_attention_capi.hip")
 KERNELS = ["_ZN2fa17fa_fwd_w64_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_causal_kernelENS_9FwdParamsE",
            "_ZN2fa24fa_fwd_w64_ragged_kernelENS_9FwdParamsE", "_ZN2fa31fa_fwd_w64_ragged_causal_kernelENS_9FwdParamsE",
-           "_ZN2fa23fa_fwd_w64_split_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_varlen_kernelENS_9FwdParamsE",
+           "_ZN2fa23fa_fwd_w64_split_kernelENS_9FwdParamsE", "_ZN2fa24fa_fwd_w64_varlen_kernelENS_9FwdParamsE", "_ZN2fa31fa_fwd_w64_varlen_causal_kernelENS_9FwdParamsE",
            "_ZN2fa16fa_fwd_hd_kernelILi256EEEvNS_9FwdParamsE",
            "_ZN2fa16fa_fwd_hd_kernelILi64EEEvNS_9FwdParamsE", "_ZN2fa23fa_fwd_hd_masked_kernelILi256EEEvNS_9FwdParamsE",
            "_ZN2fa23fa_fwd_hd_masked_kernelILi64EEEvNS_9FwdParamsE", "_ZN2fa23fa_fwd_hd_masked_kernelILi128EEEvNS_9FwdParamsE",
