@@ -60,7 +60,8 @@ def sharded_forward(q, k, v, rank: int, world: int, attention_fn: Optional[Calla
 # collective library finds no room until an attention kernel ends and the hand-off would queue behind the compute
 # instead of running beside it.  Measured on one MI355X with a transport-shaped kernel (8 workgroups x 512 threads,
 # 32 KiB LDS, 134 MB): with 8 units free it runs beside the attention kernel; a ring pass of 8 steps at
-# L = 131072 then takes 13.1 ms instead of 12.0 ms (1024 equal items no longer divide by the workgroup count).
+# L = 131072 then takes 13.1 ms instead of 12.0 ms (1024 equal items no longer divide by the workgroup count).  The last
+# step of a pass exchanges nothing and runs without the reservation.
 RING_RESERVED_CUS = 8
 
 
@@ -85,9 +86,15 @@ class _reserved_cus:
                 self.before = before
         return self
 
-    def __exit__(self, *exc):
+    def release(self):
+        """Put the reservation back early (the ring's last step: nothing travels beside it, so it gets the whole
+        chip: one step in `world` runs without the cost of the uneven rounds)."""
         if self.before is not None and self.fa.lib().fa_get_reserved_cus() == self.k:
             self.fa.set_reserved_cus(self.before)
+        self.before = None
+
+    def __exit__(self, *exc):
+        self.release()
         return False
 
 
@@ -146,10 +153,12 @@ def ring_forward(q, k, v, group=None, step_fn: Optional[Callable] = None, state_
     cur[0].copy_(k)
     cur[1].copy_(v)
     out = None
-    with _reserved_cus(reserve):
+    with _reserved_cus(reserve) as reserved:
         for s in range(world):
             last = s == world - 1
             reqs = []
+            if last:
+                reserved.release()
             if not last:
                 # issued before the compute of this step, so the transfer can run beside it (the attention kernels
                 # leave RING_RESERVED_CUS units free for its kernels); the backend orders it after the previous
@@ -244,11 +253,15 @@ def ring_forward_causal(q2, k2, v2, group=None, step_fn: Optional[Callable] = No
     if world > 1:
         box["spare"] = torch.empty_like(box["cur"])
 
+    reserved = _reserved_cus(reserve)
+
     def kv_of_step(s):
         # finish the transfer that brought this step's block, then start the next one: it
         # overlaps this step's compute, and `spare` was last read in the step before
         for r in box["reqs"]:
             r.wait()
+        if s + 1 >= world:
+            reserved.release()  # the last step exchanges nothing
         if s > 0:
             box["cur"], box["spare"] = box["spare"], box["cur"]
         box["reqs"] = []
@@ -257,5 +270,5 @@ def ring_forward_causal(q2, k2, v2, group=None, step_fn: Optional[Callable] = No
             box["reqs"] = dist.batch_isend_irecv(ops)
         return box["cur"]
 
-    with _reserved_cus(reserve):
+    with reserved:
         return run_zigzag_steps(q2, kv_of_step, rank, world, Lc, step_fn, state_factory)

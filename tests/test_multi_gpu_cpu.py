@@ -303,3 +303,31 @@ def test_bench_stdout_carries_the_json_line_only():
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"n_gpus": 1}\n'
     assert "banner" in r.stderr and "a stray print" in r.stderr
+
+
+def test_ring_reservation_is_released_early_and_puts_back_what_it_found():
+    """multi_gpu._reserved_cus: takes the units only when nobody holds any, release() (the ring's last step, which
+    exchanges nothing) and the block's end put back what was found, and a reservation somebody else made in
+    between stays."""
+    mg, _ = _load()
+    import flash_attention_amd as fa
+
+    get = fa.lib().fa_get_reserved_cus
+    fa.set_reserved_cus(0)
+    try:
+        with mg._reserved_cus(8) as r:
+            assert get() == 8
+            r.release()
+            assert get() == 0
+            r.release()  # (idempotent)
+        assert get() == 0
+        fa.set_reserved_cus(4)  # a caller's own reservation: left alone
+        with mg._reserved_cus(8):
+            assert get() == 4
+        assert get() == 4
+        fa.set_reserved_cus(0)
+        with mg._reserved_cus(8):
+            fa.set_reserved_cus(12)  # changed inside the block: theirs stays
+        assert get() == 12
+    finally:
+        fa.set_reserved_cus(0)
