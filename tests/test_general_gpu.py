@@ -1,6 +1,8 @@
 """GPU tier: fa_forward_general (sequence lengths that are not a multiple of 64, Lq != Lk, the causal
 mask of attention_cpu, testing.cu:74-77) through the C ABI against the CPU oracle on identical fp16
 inputs.  Same gate as the other parity tests: max-abs <= 2e-3, relative L2 <= 1e-3."""
+import os
+
 import numpy as np
 import pytest
 
@@ -688,6 +690,99 @@ def test_padded_batch_long_and_short_sequences_causal(fa, oracle, dev, H, fa_env
         else:
             d = (both[b, :, :n].float() - one[b, :, :n].float()).abs().max().item()
             assert 0 < d <= 2e-3, f"sequence {b}: {d}"  # (another kernel: some last bits differ)
+
+
+def test_padded_batch_of_more_sequences_than_the_planner_sorts(fa, oracle, dev, fa_env):
+    """520 sequences (the list's planner sorts up to 512 and scans 256 groups at a time): without the mask the list is
+    built in the sequences' own order; against the 128-row kernel alone on every sequence and against the oracle on a
+    few.  With the mask such a batch stays on the 128-row kernel (same bits)."""
+    import torch
+
+    B, H, L, D = 520, 1, 1216, 128
+    rng = np.random.default_rng(4500)
+    lens = [int(x) for x in rng.integers(1000, L + 1, B)]
+    lens[7], lens[300], lens[519] = L, 1100, 1099
+    Q, K, V = [rng.standard_normal((B, H, L, D), dtype=np.float32).astype(np.float16) for _ in range(3)]
+    q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
+    ql = torch.tensor(lens, dtype=torch.int32, device=dev)
+    fa_env(FA_VARLEN_W64=None)
+    both = fa.attention_varlen(q, k, v, ql, ql)
+    both_causal = fa.attention_varlen(q, k, v, ql, ql, causal=True)
+    fa_env(FA_VARLEN_W64="0")
+    one = fa.attention_varlen(q, k, v, ql, ql)
+    one_causal = fa.attention_varlen(q, k, v, ql, ql, causal=True)
+    fa_env(FA_VARLEN_W64=None)
+    torch.cuda.synchronize()
+    assert torch.equal(both_causal, one_causal)
+    tuned = _on_tuned_kernel(lens, lens, False)
+    assert sum(tuned) > 100 and not all(tuned)
+    worst = 0.0
+    for b in range(B):
+        n = lens[b]
+        assert (both[b, :, n:] == 0).all()  # (attention_varlen's own output starts as zeros)
+        if tuned[b]:
+            worst = max(worst, (both[b, :, :n].float() - one[b, :, :n].float()).abs().max().item())
+        else:
+            assert torch.equal(both[b], one[b]), f"sequence {b}"
+    assert 0 < worst <= 2e-3
+    for b in (0, 7, 300, 519):
+        n = lens[b]
+        Qs, Ks, Vs = [np.ascontiguousarray(a[b:b + 1, :, :n]) for a in (Q, K, V)]
+        gate(oracle, oracle.attention_cpu(Qs, Ks, Vs), both[b:b + 1, :, :n].cpu().numpy(), f"sequence {b} ({n} rows)")
+
+
+def test_padded_batch_masked_with_more_block_indices_than_one_scan(fa, dev, fa_env):
+    """One masked sequence of 66 001 rows (258 block indices: the planner's groups, scanned 256 at a time) beside a
+    short one: per sequence the bits of fa_forward_general on that sequence alone (the same kernel forms, the items
+    in another order)."""
+    import torch
+
+    H, D, L = 1, 128, 66001
+    lens = [L, 3000]
+    g = torch.Generator(device=dev).manual_seed(46)
+    q, k, v = [torch.randn((2, H, L, D), generator=g, device=dev).to(torch.float16) for _ in range(3)]
+    ql = torch.tensor(lens, dtype=torch.int32, device=dev)
+    fa_env(FA_VARLEN_W64=None)
+    o = fa.attention_varlen(q, k, v, ql, ql, causal=True)
+    torch.cuda.synchronize()
+    assert _on_tuned_kernel(lens, lens, True) == [True, True]
+    for b, n in enumerate(lens):
+        ref = fa.attention_general(q[b:b + 1, :, :n].contiguous(), k[b:b + 1, :, :n].contiguous(),
+                                   v[b:b + 1, :, :n].contiguous(), causal=True)
+        d = (o[b:b + 1, :, :n].float() - ref.float()).abs().max().item()
+        assert d <= 1e-3, f"sequence {b}: {d}"
+        assert (o[b, :, n:] == 0).all()
+
+
+def test_padded_batch_under_stream_capture_keeps_the_128_row_kernel(fa, dev):
+    """The list of the tuned route comes from the stream's memory pool; a capturing stream gets the 128-row kernel
+    instead, and the replayed graph gives the bits of FA_VARLEN_W64=0."""
+    import torch
+
+    B, H, L, D = 3, 2, 1300, 128
+    g = torch.Generator(device=dev).manual_seed(47)
+    q, k, v = [torch.randn((B, H, L, D), generator=g, device=dev).to(torch.float16) for _ in range(3)]
+    ql = torch.tensor([1300, 1200, 400], dtype=torch.int32, device=dev)
+    out = torch.zeros_like(q)
+    fa.attention_varlen(q, k, v, ql, ql, out=out)  # (first call outside the capture)
+    torch.cuda.synchronize()
+    eager = out.clone()
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fa.attention_varlen(q, k, v, ql, ql, out=out)
+    graph.replay()
+    torch.cuda.synchronize()
+    os.environ["FA_VARLEN_W64"] = "0"
+    fa.reload_env()
+    try:
+        plain = fa.attention_varlen(q, k, v, ql, ql)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("FA_VARLEN_W64", None)
+        fa.reload_env()
+    assert torch.equal(out, plain)
+    assert (eager.float() - plain.float()).abs().max().item() <= 2e-3
 
 
 def test_padded_batch_long_sequences_without_query_lengths(fa, oracle, dev):
