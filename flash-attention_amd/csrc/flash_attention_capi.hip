@@ -49,6 +49,7 @@ int fail(int code, const char* fmt, const char* detail = "") {
 //   FA_W64=1 / 0         the one-wave-per-SIMD kernel from three K/V tiles per item on / never (default: from five)
 //   FA_PERSISTENT=0      one workgroup per item instead of one per compute unit
 //   FA_MASKED_W64=1 / 0  masked forms of that kernel wherever they can run / nowhere (default: where measured faster)
+//   FA_VARLEN_W64=0      padded batches (fa_forward_varlen) never on that kernel's list form
 //   FA_BLOCK_TUNED=0     fa_forward_block_general keeps every block on the general kernel
 //   FA_SPLIT=0 / n       never split an item's keys over workgroups / over n of them (default: by the cost model)
 //   FA_HD=0 / 1          everything the D = 128 tuned kernels leave stays on the general kernel / only unmasked whole-tile D = 64, 256 leave it
