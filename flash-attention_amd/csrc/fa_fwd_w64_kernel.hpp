@@ -1369,6 +1369,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_varlen_causal_kernel(const 
 //   With the mask an item costs its block's diagonal, 4 (block + 1) tiles, and a group is a block index, the
 // highest first (decode_item_causal's order): the sequences that have that block are a prefix of the sorted order,
 // H entries each.  (This order needs the sort: the launcher keeps larger masked batches off this kernel.)
+//   A batch whose tuned sequences hold less than min_work rows x keys (summed over the heads), or fewer items than
+// `grid` workgroups, is left to the 128-row kernel altogether (count 0, thresholds out of reach): the launcher's rule
+// on the padded lengths, applied to the lengths themselves.
 //   Workgroup w of `grid` takes entries w, w + grid, ...: the entries are laid down in rounds of `grid`, every other
 // round back to front (the last one forwards, so that it has no holes), which hands the workgroup with the
 // costliest item of one round the cheapest of the next.  With a few items per workgroup whose costs differ by a
@@ -1378,8 +1381,8 @@ constexpr int kVarlenSortMax = 512;
 constexpr int kVarlenMaxBlocks = 4096;  // (with the mask: block indices are groups)
 __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restrict__ q_len, const int* __restrict__ k_len,
                                                              int B, int H, int lq_pad, int lk_pad, int long_q, int long_k,
-                                                             int causal, int grid, int* __restrict__ items,
-                                                             int* __restrict__ count) {
+                                                             int causal, int grid, float min_work,
+                                                             int* __restrict__ items, int* __restrict__ count) {
     __shared__ int first[kVarlenMaxBatch + 1];  // first[g]: index of group g's first entry
     __shared__ int len_q[kVarlenMaxBatch], len_k[kVarlenMaxBatch];  // valid lengths; len_k = 0: not the tuned kernel's
     __shared__ unsigned short order[kVarlenMaxBatch];               // order[r]: which sequence comes r-th
@@ -1419,10 +1422,16 @@ __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restri
         }
         __syncthreads();
     }
+    float w_tuned = wsum[0][0];
     if (wsum[0][0] > 0.0f && wsum[1][0] <= 0.25f * (wsum[0][0] + wsum[1][0])) {
         long_q = min_q;
         long_k = min_k;
+        w_tuned += wsum[1][0];
     }
+    // Too little for the list form to pay (min_work: rows x keys summed over heads and the sequences it would take;
+    // three times that with the mask, half of which is above the diagonal): it takes nothing, the 128-row kernel
+    // everything.
+    if ((float)H * w_tuned < (causal ? 3.0f : 1.0f) * min_work) long_q = long_k = 0x7fffffff;
     if (tid == 0) {
         count[1] = long_q;
         count[2] = long_k;
@@ -1473,6 +1482,13 @@ __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restri
         __syncthreads();
         if (tid == 255) carry += scan[255];
         __syncthreads();
+    }
+    if (min_work > 0.0f && carry < grid) {  // (uniform: carry is shared)
+        if (tid == 0) {
+            count[0] = 0;
+            count[1] = count[2] = 0x7fffffff;
+        }
+        return;
     }
     if (tid == 0) *count = carry;
     const int total = carry;

@@ -49,7 +49,8 @@ int fail(int code, const char* fmt, const char* detail = "") {
 //   FA_W64=1 / 0         the one-wave-per-SIMD kernel from three K/V tiles per item on / never (default: from five)
 //   FA_PERSISTENT=0      one workgroup per item instead of one per compute unit
 //   FA_MASKED_W64=1 / 0  masked forms of that kernel wherever they can run / nowhere (default: where measured faster)
-//   FA_VARLEN_W64=0      padded batches (fa_forward_varlen) never on that kernel's list form
+//   FA_VARLEN_W64=0 / 1  padded batches (fa_forward_varlen) never on that kernel's list form / whenever it can run
+//                        (default: batches large enough for it to pay)
 //   FA_BLOCK_TUNED=0     fa_forward_block_general keeps every block on the general kernel
 //   FA_SPLIT=0 / n       never split an item's keys over workgroups / over n of them (default: by the cost model)
 //   FA_HD=0 / 1          everything the D = 128 tuned kernels leave stays on the general kernel / only unmasked whole-tile D = 64, 256 leave it
@@ -64,7 +65,7 @@ struct Switches {
     bool block_tuned = true;
     int split = -1;  // -1: the cost model's choice
     bool hd = true, hd_masked = true;
-    bool varlen_w64 = true;
+    int varlen_w64 = -1;  // -1: where the batch is large enough, 1: wherever the kernel can run, 0: nowhere
 };
 std::atomic<const Switches*> g_switches{nullptr};
 std::once_flag g_switches_once;
@@ -88,7 +89,7 @@ const Switches* read_switches() {
     if (geti("FA_BLOCK_TUNED", x)) sw->block_tuned = x != 0;
     if (geti("FA_SPLIT", x) && x >= 0) sw->split = x;
     if (geti("FA_HD", x)) sw->hd = x != 0, sw->hd_masked = x != 1;
-    if (geti("FA_VARLEN_W64", x)) sw->varlen_w64 = x != 0;
+    if (geti("FA_VARLEN_W64", x)) sw->varlen_w64 = x != 0 ? 1 : 0;
     if (geti("FA_RESERVED_CUS", x) && x >= 0) g_reserved_cus.store(x, std::memory_order_relaxed);
     return sw;
 }
@@ -619,9 +620,18 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
 // half full, else 2305.  Only when the padded lengths admit a long sequence at all; not on a capturing stream (the
 // list comes from the stream's pool); with the mask only batches the planner sorts (its item order needs that) and
 // equal padded lengths; FA_VARLEN_W64=0 or FA_MASKED_W64=0 keeps everything on the 128-row kernel.
+//   The route costs a planner launch and a second attention launch (about 15 us) and hands out 256-row items to
+// one workgroup per compute unit, so it needs a batch that fills the chip: measured (tools/micro/varlen_small.py,
+// H = 16) one sequence of 4096 (256 items of 64 tiles) gains 6 %, four of 1500 (384 items of 24 tiles) lose 20 %,
+// one of 2048 loses 40 %; with the mask two of 4096 (512 items, half of their tiles above the diagonal) lose 8 %,
+// four gain 11 %.  The rule: at least one item per workgroup and 16384 item-tiles (with the mask three times
+// that), checked here on the padded lengths and again by the planner on the
+// lengths themselves (kVarlenMinWork; it leaves everything to the 128-row kernel when they fall short).
+// FA_VARLEN_W64=1 drops both checks (tests).
 // ---------------------------------------------------------------------------------------------
 constexpr int kVarlenLongRows = 1100, kVarlenLongCausalFull = 1665, kVarlenLongCausal = 2305;
-bool varlen_on_w64(int B, int Lq, int Lk, int D, int flags, hipStream_t stream) {
+constexpr long kVarlenMinItemTiles = 16384;
+bool varlen_on_w64(int B, int H, int Lq, int Lk, int D, int flags, hipStream_t stream) {
     const Switches& sw = switches();
     if (D != fa::kHeadDim || (flags & ~FA_FLAG_CAUSAL)) return false;
     if (flags & FA_FLAG_CAUSAL) {
@@ -630,7 +640,12 @@ bool varlen_on_w64(int B, int Lq, int Lk, int D, int flags, hipStream_t stream) 
     } else if (Lq < kVarlenLongRows || Lk < kVarlenLongRows) {
         return false;
     }
-    if (B > fa::kVarlenMaxBatch || !sw.varlen_w64 || sw.masked_w64 == 0 || !sw.persistent) return false;
+    if (B > fa::kVarlenMaxBatch || sw.varlen_w64 == 0 || sw.masked_w64 == 0 || !sw.persistent) return false;
+    if (sw.varlen_w64 < 0) {
+        const long items = (long)B * H * ((Lq + 255) / 256), tiles = (Lk + fa::kKvTile - 1) / fa::kKvTile;
+        if (items < persistent_grid() || items * tiles < ((flags & FA_FLAG_CAUSAL) ? 3 : 1) * kVarlenMinItemTiles)
+            return false;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
     return true;
@@ -656,7 +671,8 @@ int launch_varlen_long_and_short(const fa::FwdParams& base, int B, int H, hipStr
     long grid = persistent_grid();
     if (grid > max_items) grid = max_items;
     hipLaunchKernelGGL(fa::fa_varlen_plan_kernel, dim3(1), dim3(256), 0, stream, base.q_len, base.k_len, B, H, base.lq,
-                       base.lk, p.long_q, p.long_k, causal ? 1 : 0, (int)grid, items, count);
+                       base.lk, p.long_q, p.long_k, causal ? 1 : 0, (int)grid,
+                       switches().varlen_w64 < 0 ? (float)kVarlenMinItemTiles * 16384.0f : 0.0f, items, count);
     if (causal)
         hipLaunchKernelGGL(fa::fa_fwd_w64_varlen_causal_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     else
@@ -919,7 +935,7 @@ int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV
     p.k_len = d_k_len;
     p.heads_per_batch = H;
     if (switches().hd && switches().hd_masked) {
-        if (varlen_on_w64(B, Lq, Lk, D, flags, stream))
+        if (varlen_on_w64(B, H, Lq, Lk, D, flags, stream))
             return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_varlen_long_and_short(p, B, H, stream); });
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_maybe_split(p, D, kHdMasked, stream); });
     }

@@ -22,7 +22,8 @@ the padding and a sentinel in the output, three kinds of shapes: self-attention 
 causal mask), different query and key lengths (the causal mask counted from each sequence's start), and decoding
 batches of 1 to 16 query rows against up to 8000 keys, which the launcher divides into key ranges.  Per sequence
 the oracle runs on the truncated tensors; rows behind q_len must keep the sentinel, a sequence without keys gives 0."""
-import argparse, os, sys
+import argparse
+import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -35,6 +36,7 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--tiles", action="store_true")
 ap.add_argument("--varlen", action="store_true")
 args = ap.parse_args()
+os.environ.setdefault("FA_VARLEN_W64", "1")  # (small batches: the tuned kernel's list form wherever it can run)
 fa = ge.load_package()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(args.seed)
