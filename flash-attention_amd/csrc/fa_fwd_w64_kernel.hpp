@@ -609,6 +609,21 @@ __device__ __forceinline__ void fine_stamp(unsigned& sv0, unsigned& sv1, int idx
     else
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(sv1) : "s"(lo), "s"(idx - 64) : "m0");
 }
+// The same inside a phase (-DW64_GAP_STAMP=g -DW64_GAP_STAMP_PHASE=1|2: one stamp in gap g of that phase, kept in the
+// slot of the phase's end stamp, which such a build leaves out): m0, the lane select, belongs to the tile transfers
+// there and is put back.  The counter is sampled when the instruction issues; the wait for its
+// result follows and is not part of the value.
+__device__ __forceinline__ void gap_stamp(unsigned& sv0, unsigned& sv1, int idx) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned lo = (unsigned)t;
+    unsigned keep;
+    if (idx < 64)
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                     : "+v"(sv0), "=&s"(keep) : "s"(lo), "s"(idx));
+    else
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                     : "+v"(sv1), "=&s"(keep) : "s"(lo), "s"(idx - 64));
+}
 #endif
 
 // Causal item order.  With the mask of attention_cpu (testing.cu:74-77: key <= query row) query block qb
@@ -1168,6 +1183,13 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
 #endif
         };
         auto dma_none = [&](auto) {};
+        auto xdma_phase2 = [&](auto gc) {
+#if defined(W64_FINE_STAMPS) && defined(W64_GAP_STAMP)
+            constexpr int gx = decltype(gc)::value;
+            if constexpr (W64_GAP_STAMP_PHASE == 2 && gx == W64_GAP_STAMP)
+                if (gs >= W64_FINE_STAMPS && gs < W64_FINE_STAMPS + 18) gap_stamp(sv0, sv1, 7 * (gs - W64_FINE_STAMPS) + 4);
+#endif
+        };
         // ---- QSTREAM: this step's four extra pieces (gaps 0, 1, 15, 16: one per gap, the LDS base set in the first
         //      of each pair; the tile transfers set their own bases in gaps 2 and 18)
         [[maybe_unused]] unsigned x_base = k_dst;
@@ -1185,6 +1207,10 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         }
         auto xdma_step = [&](auto gc) {
             constexpr int gx = decltype(gc)::value;
+#if defined(W64_FINE_STAMPS) && defined(W64_GAP_STAMP)
+            if constexpr (W64_GAP_STAMP_PHASE == 1 && gx == W64_GAP_STAMP)
+                if (gs >= W64_FINE_STAMPS && gs < W64_FINE_STAMPS + 18) gap_stamp(sv0, sv1, 7 * (gs - W64_FINE_STAMPS) + 2);
+#endif
             if constexpr (QSTREAM && (gx == 0 || gx == 1 || gx == 15 || gx == 16)) {
                 constexpr int e = gx < 2 ? gx : gx - 13;
                 if constexpr (gx == 0 || gx == 15) dma_set_base(x_base);
@@ -1243,7 +1269,7 @@ __device__ __forceinline__ void fa_fwd_w64_body(const FwdParams& p) {
         W64_STAMP(3);
 #endif
         fused_phase<false, kAccA, kQregA, 0, 0>(
-            w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none);
+            w, kb0, kb1, sa0, sa1, pa, mx_a, ra.m_run, need_a, sb0, sb1, rb.m_run, rb.l_run, pb, c, dma_none, xdma_phase2);
 #ifndef W64_STAMP_WO
         W64_STAMP(4);
 #endif
