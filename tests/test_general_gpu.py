@@ -709,6 +709,7 @@ def test_padded_batch_of_more_sequences_than_the_planner_sorts(fa, oracle, dev, 
     ql = torch.tensor(lens, dtype=torch.int32, device=dev)
     fa_env(FA_VARLEN_W64=None)
     both = fa.attention_varlen(q, k, v, ql, ql)
+    assert torch.equal(both, fa.attention_varlen(q, k, v, ql, ql))  # (fixed item lists: the same bits every time)
     both_causal = fa.attention_varlen(q, k, v, ql, ql, causal=True)
     fa_env(FA_VARLEN_W64="0")
     one = fa.attention_varlen(q, k, v, ql, ql)
