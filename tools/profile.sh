@@ -36,6 +36,26 @@ for f in glob.glob(sys.argv[1] + "/pmc_*/*/*_counter_collection.csv"):
     w = csv.DictWriter(open(f, "w", newline=""), fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
     w.writeheader(); w.writerows(keep)
 PY
+# the timed region by itself: the attention kernel's last STEPS launches in the trace (what the bench timed; the
+# stats file averages over the preheat as well, where the clock is still coming up), and the line the bench
+# printed in the same run
+python3 - "$OUT" "$STEPS" <<'PY'
+import csv, glob, json, sys
+out, steps = sys.argv[1], int(sys.argv[2])
+f = glob.glob(out + "/trace/*/*_kernel_trace.csv")[0]
+rows = [r for r in csv.DictReader(open(f)) if "fa_fwd_w64" in r["Kernel_Name"] or "fa_fwd_ring" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+last = rows[-steps:]
+dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
+span = (int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])) / len(last)
+line = [l for l in open(out + "/trace.log") if l.startswith("{")]
+bench = json.loads(line[-1]) if line else {}
+json.dump({"timed_launches": len(last), "timed_kernel_us_avg": sum(dur) / len(dur) / 1e3, "timed_kernel_us_min": min(dur) / 1e3,
+           "timed_period_us": span / 1e3, "bench_line_ms_per_step": bench.get("ms_per_step"),
+           "bench_line_kernel_ms": (bench.get("roofline") or {}).get("kernel_ms"), "bench_line_value": bench.get("value")},
+          open(out + "/trace_timed.json", "w"), indent=1)
+print(open(out + "/trace_timed.json").read())
+PY
 rm -f "$OUT"/trace/*/*_kernel_trace.csv
 find "$OUT" -name "*.csv" | head -20
 echo "profile passes done for $TAG"

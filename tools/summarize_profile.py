@@ -103,6 +103,11 @@ def main():
         "algorithmic_bytes": 4.0 * B * H * L * D * 2,
         "hbm_GBps_at_avg": (read_b + write_b) / avg_ns,
     }
+    timed = os.path.join(src, "trace_timed.json")
+    if os.path.exists(timed):
+        # the bench's timed region inside the trace pass: its launches' own durations, their period (launch to
+        # launch) and the line the bench printed in that run (wall clock per step, HIP-event time per launch)
+        out["timed_region_of_the_trace_pass"] = json.load(open(timed))
     if "TCC_HIT_sum" in tcc and "TCC_MISS_sum" in tcc:
         out["l2_hit_rate"] = tcc["TCC_HIT_sum"] / max(1.0, tcc["TCC_HIT_sum"] + tcc["TCC_MISS_sum"])
     path = os.path.join(dst, f"{rnd}_{tag}.json")
