@@ -151,7 +151,8 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
  * sequence without keys gets O = 0.  At D = 128 the long sequences of a batch (without the mask at least 1100 query
  * rows and keys; with it as many rows as keys and at least 1665, 2305 when the last 256-row block is at most half
  * full; padded lengths that admit such a sequence) run on the default kernel's ragged forms from a device-built item
- * list (a few KiB from the stream's memory pool, hipMallocAsync; not on a stream under capture), the others after
+ * list (16 bytes per head and 256-row block of the padded batch, from the stream's memory pool, hipMallocAsync;
+ * not on a stream under capture), the others after
  * them on the 128-row kernel, unless they hold so little of the work that they join the list; batches too small
  * to fill the chip that way stay on the 128-row kernel.  FA_VARLEN_W64=0 in the environment keeps all on the
  * 128-row kernel, 1 takes the list form wherever it can run.  With FA_FLAG_CAUSAL key j is visible to query i iff j <= i (both counted from
