@@ -148,15 +148,16 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
  * attention_cpu gives on the truncated tensors: its 64-key tiles end at the sequence's last key
  * (testing.cu:65-66).  d_q_len and d_k_len are DEVICE arrays of B ints, read by the kernel (no host
  * synchronisation); either may be NULL (= Lq, Lk for every sequence); values are clamped to [0, Lq] and [0, Lk]; a
- * sequence without keys gets O = 0.  At D = 128 the long sequences of a batch (without the mask at least 1100 query
- * rows and keys; with it as many rows as keys and at least 1665, 2305 when the last 256-row block is at most half
- * full; padded lengths that admit such a sequence) run on the default kernel's ragged forms from a device-built item
- * list (16 bytes per head and 256-row block of the padded batch, from the stream's memory pool, hipMallocAsync;
- * not on a stream under capture), the others after
- * them on the 128-row kernel, unless they hold so little of the work that they join the list; batches too small
- * to fill the chip that way stay on the 128-row kernel.  FA_VARLEN_W64=0 in the environment keeps all on the
- * 128-row kernel, 1 takes the list form wherever it can run.  With FA_FLAG_CAUSAL key j is visible to query i iff j <= i (both counted from
- * the sequence's start; Lq and Lk may differ).  D of 64, 128 or 256.  The reference has no mask of this kind: its
+ * sequence without keys gets O = 0.  With FA_FLAG_CAUSAL key j is visible to query i iff j <= i (both counted from
+ * the sequence's start; Lq and Lk may differ).  D of 64, 128 or 256.
+ *   At D = 128 the long sequences of a batch (without the mask at least 1100 query rows and keys; with it as many
+ * rows as keys and at least 1665, or 2305 when the last 256-row block is at most half full) run on the default
+ * kernel's ragged forms from a device-built item list (16 bytes per head and 256-row block of the padded batch, from
+ * the stream's memory pool, hipMallocAsync; not on a stream under capture), the other sequences after them on the
+ * 128-row kernel, unless they hold so little of the work that they join the list; batches too small to fill the
+ * chip that way stay on the 128-row kernel.  FA_VARLEN_W64=0 in the environment keeps everything on the 128-row
+ * kernel, 1 takes the list form wherever it can run.
+ *   The reference has no mask of this kind: its
  * README lists "causal and padding masks" as future work (README.md:44), its naive kernel knows the causal one
  * only (normal_attention.cu:50,64,81). */
 int fa_forward_varlen(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int Lq,
