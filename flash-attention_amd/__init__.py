@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "fa_version",
     "fa_kernel_name",
     "fa_kernel_name_general",
+    "fa_kernel_name_general_bh",
     "fa_kernel_name_block_general",
     "fa_split_ways",
     "fa_split_ways_general",
@@ -121,6 +122,8 @@ def bind(path: str) -> ct.CDLL:
     L.fa_kernel_name.restype = ct.c_char_p
     L.fa_kernel_name_general.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int]
     L.fa_kernel_name_general.restype = ct.c_char_p
+    L.fa_kernel_name_general_bh.argtypes = [ct.c_int] * 5
+    L.fa_kernel_name_general_bh.restype = ct.c_char_p
     L.fa_kernel_name_block_general.argtypes = [ct.c_int] * 6
     L.fa_kernel_name_block_general.restype = ct.c_char_p
     L.fa_split_ways.argtypes = [ct.c_int] * 3

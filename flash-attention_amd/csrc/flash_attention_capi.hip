@@ -568,7 +568,24 @@ int launch_hd_maybe_split(const fa::FwdParams& p, int D, HdRoute r, hipStream_t 
 // 15 % slower on short sequences) from Lq = 1665 on when the last block holds more than 128 rows, else from 2305.
 // FA_MASKED_W64=1 takes them wherever they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests; see
 // Switches).
-bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false) {
+// Unmasked ragged lengths, with the batch known: both kernels' times from a model of each, fitted to
+// tools/micro/ragged_rule.py (27 lengths from 193 to 1535 with 1 ... 255 rows in the last block, B * L = 16384, H = 16;
+// it reproduces the tuned kernel's times within 3 % and picks the faster kernel at 26 of the 27, the miss being a
+// 2 % difference).  The tuned kernel runs whole rounds of 256-row items, one per compute unit, each costing its
+// tiles and 3.6 us of item boundary; the 128-row kernel runs two workgroups per unit with no rounds to speak of
+// and 14 us more of fixed cost.  So 511, 767 or 1023 rows in a batch that makes whole rounds are 13 % faster on
+// the tuned kernel, and 513 rows 13 % slower: a threshold on the length alone cannot say that.  Only where both
+// kernels fill the chip; elsewhere (and without the batch: bh = 0) the threshold stays.
+bool ragged_w64_faster(long bh, int lq, int lk) {
+    const long grid = persistent_grid(), cus = device_cus();
+    const long items256 = bh * ((lq + 255) / 256), items128 = bh * ((lq + 127) / 128);
+    if (items256 < grid || items128 < 2 * cus) return lq >= 1100;
+    const double rounds = (double)((items256 + grid - 1) / grid);
+    const double t_w64 = 8.0 + rounds * (1.33 * ((lk + 63) / 64) + 3.6);
+    const double t_hd = 22.4 + (double)items128 / (2.0 * cus) * (0.8535 * ((lk + 31) / 32) + 0.094);
+    return t_w64 < t_hd;
+}
+bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false, long bh = 0) {
     const bool causal = (flags & FA_FLAG_CAUSAL) != 0;
     if (D != fa::kHeadDim || lq < 64 || lk < 3 * fa::kKvTile || (causal && lq != lk)) return false;
     if (!causal && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return false;  // the unmasked kernels' shapes
@@ -578,7 +595,7 @@ bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false) {
         if (!causal) return lq >= 512 || last_block_rows > 128;
         return lq >= 1088 || (lq >= 385 && last_block_rows > 128) || lq == 192 || lq == 256;
     }
-    if (!causal) return lq >= 1100;
+    if (!causal) return bh > 0 ? ragged_w64_faster(bh, lq, lk) : lq >= 1100;
     if (lq % fa::kKvTile == 0) return lq >= 1920 || (last_block_rows >= 192 && (lq >= 960 || lq == 512));
     return lq >= (last_block_rows > 128 ? 1665 : 2305);
 }
@@ -806,7 +823,7 @@ int fa_split_ways(int bh, int lq, int lk) {
 int fa_split_ways_general(int bh, int lq, int lk, int D, int flags) {
     if (bh <= 0 || lq <= 0 || lk <= 0 || flags != 0 || (D != 64 && D != 128 && D != 256)) return 1;
     if (D == fa::kHeadDim && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0) return fa_split_ways(bh, lq, lk);
-    if (masked_on_w64(flags, D, lq, lk) || !hd_route(flags, D, lq, lk)) return 1;
+    if (masked_on_w64(flags, D, lq, lk, false, bh) || !hd_route(flags, D, lq, lk)) return 1;
     int lk_split = 0;
     return pick_hd_split(bh, lq, lk, D, &lk_split);
 }
@@ -825,10 +842,10 @@ const char* fa_kernel_name_block_general(int lq, int lk, int D, int flags, int q
             return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
     }
 }
-const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
+const char* fa_kernel_name_general_bh(int bh, int lq, int lk, int D, int flags) {
     if (flags == 0 && D == fa::kHeadDim && lq > 0 && lk > 0 && lq % fa::kKvTile == 0 && lk % fa::kKvTile == 0)
         return fa_kernel_name(lq, lk);
-    if (masked_on_w64(flags, D, lq, lk)) {
+    if (masked_on_w64(flags, D, lq, lk, false, bh)) {
         fa::FwdParams p{};
         p.lq = lq, p.lk = lk, p.flags = (flags & FA_FLAG_CAUSAL) ? fa::kFlagCausal : 0;
         return masked_w64_name(p);
@@ -836,6 +853,7 @@ const char* fa_kernel_name_general(int lq, int lk, int D, int flags) {
     if (const HdRoute r = hd_route(flags, D, lq, lk)) return hd_name(r, D);
     return D == 64 ? "fa::fa_fwd_general_kernel<64>" : D == 256 ? "fa::fa_fwd_general_kernel<256>" : "fa::fa_fwd_general_kernel<128>";
 }
+const char* fa_kernel_name_general(int lq, int lk, int D, int flags) { return fa_kernel_name_general_bh(0, lq, lk, D, flags); }
 
 int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dO, int B, int H, int L,
                int D, int tile, void* stream_, float* elapsed_ms) {
@@ -899,7 +917,7 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
         p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)D);
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch(p, stream, Workspace::kStream); });
     }
-    if (masked_on_w64(flags, D, Lq, Lk))
+    if (masked_on_w64(flags, D, Lq, Lk, false, (long)B * H))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_w64_masked(p, stream); });
     if (const HdRoute r = hd_route(flags, D, Lq, Lk))
         return timed_launch(stream, elapsed_ms, [&]() -> int { return launch_hd_maybe_split(p, D, r, stream); });

@@ -234,8 +234,12 @@ const char* fa_kernel_name(int lq, int lk);
  * on the current device (1: no split; then fa_kernel_name names the only kernel, otherwise
  * fa::fa_fwd_w64_split_kernel runs, followed by fa::fa_split_merge_kernel). */
 int fa_split_ways(int bh, int lq, int lk);
-/* The same for a call of fa_forward_general (flags as there). */
+/* The same for a call of fa_forward_general (flags as there).  For unmasked lengths that are not whole tiles at
+ * D = 128 the choice between the ragged form of the default kernel and the 128-row kernel also depends on the batch
+ * (whole rounds of 256-row items or not): fa_kernel_name_general_bh takes B*H as well and names the kernel the call
+ * launches; without it (bh = 0) the answer is the one for batches that do not fill the chip. */
 const char* fa_kernel_name_general(int lq, int lk, int D, int flags);
+const char* fa_kernel_name_general_bh(int bh, int lq, int lk, int D, int flags);
 /* Into how many key ranges a call of fa_forward_general divides each head when fa_kernel_name_general names one of the
  * fa::fa_fwd_hd_* kernels (a handful of query rows against a long sequence, or few heads: too few workgroups to fill
  * the chip); 1: no split; otherwise fa::fa_fwd_hd_state_kernel<D> runs on the ranges, followed by

@@ -213,6 +213,37 @@ def test_ragged_lengths_on_the_tuned_kernel(fa, oracle, dev, Lq, Lk, causal, fa_
     assert np.array_equal(O, O2)  # rows computed by two waves are stored by one: repeats are bit-exact
 
 
+def test_unmasked_ragged_lengths_are_routed_by_the_batch(fa, oracle, dev, fa_env):
+    """D = 128, no mask, lengths that are not whole tiles: with the batch known the launcher compares a cost model of
+    the ragged tuned kernel (whole rounds of 256-row items) with one of the 128-row kernel.  32 x 16 heads of 511 rows
+    are four whole rounds and go to the tuned kernel, 513 rows (a third block of one row) to the 128-row kernel;
+    a batch that does not fill the chip keeps the length threshold (1100).  Either way the oracle's result."""
+    import torch
+
+    fa_env(FA_MASKED_W64=None, FA_HD=None)
+    name = fa.lib().fa_kernel_name_general_bh
+    assert name(512, 511, 511, 128, 0) == b"fa::fa_fwd_w64_ragged_kernel"
+    assert name(512, 513, 513, 128, 0) == b"fa::fa_fwd_hd_masked_kernel<128>"
+    assert name(512, 1023, 1023, 128, 0) == b"fa::fa_fwd_w64_ragged_kernel"
+    assert name(6, 511, 511, 128, 0) == b"fa::fa_fwd_hd_masked_kernel<128>" == fa.lib().fa_kernel_name_general(511, 511, 128, 0)
+    assert name(6, 1100, 1100, 128, 0) == b"fa::fa_fwd_w64_ragged_kernel"
+    B, H, L = 32, 16, 511
+    g = torch.Generator(device=dev).manual_seed(49)
+    q, k, v = [torch.randn((B, H, L, 128), generator=g, device=dev).to(torch.float16) for _ in range(3)]
+    o = fa.attention_general(q, k, v)
+    fa_env(FA_MASKED_W64="0")
+    o_hd = fa.attention_general(q, k, v)
+    fa_env(FA_MASKED_W64=None)
+    torch.cuda.synchronize()
+    d = (o.float() - o_hd.float()).abs().max().item()
+    assert 0 < d <= 2e-3, d  # (two kernels)
+    sl = slice(5, 7)
+    Q, K, V = [np.ascontiguousarray(t[sl].cpu().numpy()) for t in (q, k, v)]
+    st = oracle.BlockState(2, H, L, 128)
+    oracle.block_update(st, Q, K, V)
+    gate(oracle, oracle.block_finalize(st), o[sl].cpu().numpy(), "511 rows on the ragged tuned kernel, routed by the batch")
+
+
 @pytest.mark.parametrize("B,H,L,causal", [(9, 16, 1000, False), (7, 21, 705, True), (4, 16, 2100, True)])
 def test_ragged_tuned_kernel_many_items(fa, oracle, dev, B, H, L, causal, fa_env):
     """Several items per workgroup with ragged lengths: every row against the general kernel, sampled rows
