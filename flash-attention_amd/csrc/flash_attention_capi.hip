@@ -565,7 +565,8 @@ int launch_hd_maybe_split(const fa::FwdParams& p, int D, HdRoute r, hipStream_t 
 // alternative everywhere else), which is 15 - 30 % faster than the general kernel on short sequences: without
 // the mask from Lq = 1100 on; with the mask in whole tiles from Lq = 1920 on, and from 960 on (and at 512) when
 // the last block holds at least 192 rows; with the mask and ragged lengths (their form of the kernel is some
-// 15 % slower on short sequences) from Lq = 1665 on when the last block holds more than 128 rows, else from 2305.
+// 15 % slower on short sequences) from Lq = 960 on when the last block holds at least 192 rows, from 1665 on when it
+// holds more than 128, else from 2305 (tools/micro/ragged_rule.py --causal).
 // FA_MASKED_W64=1 takes them wherever they can run, FA_MASKED_W64=0 nowhere (A/B comparisons, tests; see
 // Switches).
 // Unmasked ragged lengths, with the batch known: both kernels' times from a model of each, fitted to
@@ -597,6 +598,7 @@ bool masked_on_w64(int flags, int D, int lq, int lk, bool blockwise = false, lon
     }
     if (!causal) return bh > 0 ? ragged_w64_faster(bh, lq, lk) : lq >= 1100;
     if (lq % fa::kKvTile == 0) return lq >= 1920 || (last_block_rows >= 192 && (lq >= 960 || lq == 512));
+    if (last_block_rows >= 192 && lq >= 960) return true;  // (as in whole tiles: 1023 and 1535 rows run 5 - 10 % faster here)
     return lq >= (last_block_rows > 128 ? 1665 : 2305);
 }
 // (which of its instantiations: by the mask flag and by whether both lengths are whole tiles)

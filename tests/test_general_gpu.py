@@ -121,9 +121,9 @@ def test_masked_kernel_choice(fa, fa_env):
     general = b"fa::fa_fwd_hd_masked_kernel<128>"
     fa_env(FA_HD=None)
     fa_env(FA_MASKED_W64=None)
-    for L in (512, 960, 1024, 1216, 1700, 1920, 2048, 2305, 16383, 16384):
+    for L in (512, 960, 1000, 1023, 1024, 1216, 1535, 1700, 1920, 2048, 2305, 16383, 16384):
         assert name(L, L, 128, 1) == masked_tuned(L, L, True)
-    for L in (64, 128, 192, 193, 256, 320, 384, 448, 500, 576, 640, 700, 768, 1000, 1025, 1088, 1344, 1537, 1793, 2049):
+    for L in (64, 128, 192, 193, 256, 320, 384, 448, 500, 576, 640, 700, 768, 959, 1025, 1088, 1344, 1537, 1793, 2049):
         assert name(L, L, 128, 1) == general
     for Lq, Lk in ((2047, 2047), (1100, 320), (1153, 1153), (16383, 16383)):
         assert name(Lq, Lk, 128, 0) == masked_tuned(Lq, Lk, False)

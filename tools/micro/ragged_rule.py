@@ -12,7 +12,7 @@ fa = ge.load_package()
 dev = torch.device("cuda:0")
 H, D = 16, 128
 causal = "--causal" in sys.argv
-n = 16384 * H * D + 8192 * H * D
+n = 16384 * H * D + 16384 * H * D
 buf = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(4)]
 for t, seed in zip(buf[:3], (1234, 2345, 3456)):
     fa.init_half(t, seed)
@@ -42,8 +42,9 @@ def run(L, tuned):
     return e0.elapsed_time(e1) / 20 * 1e3
 
 
-for base in (0, 256, 512, 768, 1024, 1280):
-    for r in (1, 65, 129, 193, 255):
+bases = (0, 256, 512, 768, 1024, 1280) if not causal else (0, 256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304, 2560)
+for base in bases:
+    for r in ((1, 65, 129, 193, 255) if not causal else (1, 64, 129, 192, 255, 256)):  # (with the mask whole tiles count too)
         L = base + r
         if L < 192:
             continue
