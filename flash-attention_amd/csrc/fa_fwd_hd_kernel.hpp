@@ -377,7 +377,7 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
         if (qb * QB >= lq_v) return;  // (uniform over the workgroup, before its first barrier or transfer)
         // (a padded batch whose long sequences run on the fa_fwd_w64_varlen kernels, launched before this one: the list's
         // planner left this launch's thresholds behind the item count)
-        if (p.long_q > 0 && varlen_on_tuned(lq_v, lk_v, p.varlen_count[1], p.varlen_count[2], causal)) return;
+        if (p.long_q != 0 && varlen_on_tuned(lq_v, lk_v, p.varlen_count[1], p.varlen_count[2], causal)) return;
     }
     const int q_row0 = qb * QB + wave * kRowsPerWave;   // wave-uniform
     const bool wave_valid = q_row0 < lq_v;              // a wave past the last row computes along and stores nothing

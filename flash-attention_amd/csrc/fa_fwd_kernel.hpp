@@ -64,13 +64,30 @@ enum : int {
 };
 
 // Padded batches at D = 128: which sequences run on the tuned kernel's list form (fa_fwd_w64_varlen kernels) and which on the
-// 128-row kernel launched beside it; both kernels and the list's planner ask this.  Without the mask: at least
-// long_q query rows and long_k keys.  With it: the same count of rows and keys (the tuned kernels' mask assumes
-// it), and at least long_q of them when the last 256-row block holds more than 128 rows, long_k otherwise (a last
-// block that is mostly idle weighs more on the 256-row items).
+// 128-row kernel launched beside it; both kernels and the list's planner ask this.
+//   Without the mask, long_q = kVarlenByCost: by what the sequence costs on either kernel per head, in microseconds of
+// one compute unit (the launcher's models of the two kernels, fitted to tools/micro/ragged_rule.py): 256-row items of
+// 1.33 us per 64-key tile plus 3.6 us each, against 128-row workgroups, two to a unit, of 0.85 us per 32-key tile.
+// A last block that is mostly empty weighs on the 256-row items, short key ranges on their fixed cost: 640 rows
+// and keys are a tie, 700 go to the tuned kernel, 513 do not.  Any other long_q: at least long_q query rows and
+// long_k keys.
+//   With the mask: the same count of rows and keys (the tuned kernels' mask assumes it), and at least long_q of
+// them when the last 256-row block holds more than 128 rows, long_k otherwise (a last block that is mostly idle
+// weighs more on the 256-row items); with the standing thresholds also from 960 rows on when the last block
+// holds at least 192 (as the launcher's rule for single sequences).
+constexpr int kVarlenByCost = -1;
 __host__ __device__ inline bool varlen_on_tuned(int ql, int kl, int long_q, int long_k, bool causal) {
-    if (!causal) return ql >= long_q && kl >= long_k;
-    return ql == kl && ql >= (((ql - 1) & 255) + 1 > 128 ? long_q : long_k);
+    if (!causal) {
+        if (long_q != kVarlenByCost) return ql >= long_q && kl >= long_k;
+        if (ql < 64 || kl < 192) return false;
+        const float tuned = (float)((ql + 255) / 256) * (1.33f * (float)((kl + 63) / 64) + 3.6f);
+        const float rows128 = 0.5f * (float)((ql + 127) / 128) * (0.8535f * (float)((kl + 31) / 32) + 0.094f);
+        return tuned < rows128;
+    }
+    if (ql != kl) return false;
+    const int last_rows = ((ql - 1) & 255) + 1;
+    if (long_q == 1665 && last_rows >= 192 && ql >= 960) return true;
+    return ql >= (last_rows > 128 ? long_q : long_k);
 }
 
 struct FwdParams {

@@ -1455,9 +1455,9 @@ __global__ __launch_bounds__(256) void fa_varlen_plan_kernel(const int* __restri
         w_tuned += wsum[1][0];
     }
     // Too little for the list form to pay (min_work: rows x keys summed over heads and the sequences it would take;
-    // three times that with the mask, half of which is above the diagonal): it takes nothing, the 128-row kernel
+    // twice that with the mask, half of which is above the diagonal): it takes nothing, the 128-row kernel
     // everything.
-    if ((float)H * w_tuned < (causal ? 3.0f : 1.0f) * min_work) long_q = long_k = 0x7fffffff;
+    if ((float)H * w_tuned < (causal ? 2.0f : 1.0f) * min_work) long_q = long_k = 0x7fffffff;
     if (tid == 0) {
         count[1] = long_q;
         count[2] = long_k;

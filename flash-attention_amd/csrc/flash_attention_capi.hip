@@ -634,35 +634,40 @@ int launch_w64_masked(const fa::FwdParams& base, hipStream_t stream) {
 // fa_fwd_w64_varlen_causal_kernel: items with their own lengths from a list that fa_varlen_plan_kernel builds on the
 // device, where the lengths are), the batch's other sequences on the 128-row kernel, which leaves the long ones
 // alone; both launches cover the whole batch and sort the sequences out themselves (fa::varlen_on_tuned).  The
-// thresholds are where the ragged tuned forms overtake the 128-row kernel on single sequences (masked_on_w64):
-// without the mask 1100 query rows and keys; with it 1665 rows = keys when the last 256-row block is more than
-// half full, else 2305.  Only when the padded lengths admit a long sequence at all; not on a capturing stream (the
+// split: without the mask by each sequence's cost on either kernel (fa::varlen_on_tuned: about 640 rows and keys
+// with a well-filled last block); with it where the ragged tuned forms overtake the 128-row kernel on single
+// sequences (masked_on_w64): 1665 rows = keys when the last 256-row block is more than half full (960 when it
+// holds 192 rows or more), else 2305.  Only when the padded lengths admit a long sequence at all; not on a capturing stream (the
 // list comes from the stream's pool); with the mask only batches the planner sorts (its item order needs that) and
 // equal padded lengths; FA_VARLEN_W64=0 or FA_MASKED_W64=0 keeps everything on the 128-row kernel.
 //   The route costs a planner launch and a second attention launch (about 15 us) and hands out 256-row items to
-// one workgroup per compute unit, so it needs a batch that fills the chip: measured (tools/micro/varlen_small.py,
-// H = 16) one sequence of 4096 (256 items of 64 tiles) gains 6 %, four of 1500 (384 items of 24 tiles) lose 20 %,
-// one of 2048 loses 40 %; with the mask two of 4096 (512 items, half of their tiles above the diagonal) lose 8 %,
-// four gain 11 %.  The rule: at least one item per workgroup and 16384 item-tiles (with the mask three times
-// that), checked here on the padded lengths and again by the planner on the
-// lengths themselves (kVarlenMinWork; it leaves everything to the 128-row kernel when they fall short).
+// one workgroup per compute unit, and it wins 10 - 15 % on what the tuned kernel takes: it pays from about 150 us of
+// work on.  Measured (tools/bench_varlen.py, tools/micro/varlen_small.py, H = 16): 8 sequences of 2048 (1024 items of
+// 32 tiles) gain 7 - 9 %, 16 of 64 ... 2048 (22 000 item-tiles) lose 7 %, one of 4096 (16 384) gains 6 %, four of
+// 1500 lose 20 %; with the mask four of 4096 gain 13 %, two lose 8 %.  The rule: at least one item per workgroup
+// and 32768 item-tiles (with the mask twice that: half of them lie above the diagonal) by the padded lengths.  The
+// planner checks the lengths themselves, but only for batches that are mostly padding (one item per workgroup,
+// 8192 item-tiles): by then its own launch is paid for, and leaving everything to the 128-row kernel costs an
+// empty launch of the tuned kernel on top (measured: one sequence of 4096 among 15 of 200 runs in 124 - 127 us on
+// the route, 129 without it and 139 when the planner turns the route down).
 // FA_VARLEN_W64=1 drops both checks (tests).
 // ---------------------------------------------------------------------------------------------
-constexpr int kVarlenLongRows = 1100, kVarlenLongCausalFull = 1665, kVarlenLongCausal = 2305;
-constexpr long kVarlenMinItemTiles = 16384;
+constexpr int kVarlenLongCausalFull = 1665, kVarlenLongCausal = 2305;
+constexpr int kVarlenShortestRows = 600;  // (without the mask the split is by cost: no shorter sequence can win)
+constexpr long kVarlenMinItemTiles = 32768, kVarlenMinItemTilesPlanned = 8192;
 bool varlen_on_w64(int B, int H, int Lq, int Lk, int D, int flags, hipStream_t stream) {
     const Switches& sw = switches();
     if (D != fa::kHeadDim || (flags & ~FA_FLAG_CAUSAL)) return false;
     if (flags & FA_FLAG_CAUSAL) {
         if (Lq != Lk || Lq < kVarlenLongCausalFull || B > fa::kVarlenSortMax) return false;
         if ((Lq + 255) / 256 > fa::kVarlenMaxBlocks) return false;
-    } else if (Lq < kVarlenLongRows || Lk < kVarlenLongRows) {
+    } else if (Lq < kVarlenShortestRows || Lk < kVarlenShortestRows) {
         return false;
     }
     if (B > fa::kVarlenMaxBatch || sw.varlen_w64 == 0 || sw.masked_w64 == 0 || !sw.persistent) return false;
     if (sw.varlen_w64 < 0) {
         const long items = (long)B * H * ((Lq + 255) / 256), tiles = (Lk + fa::kKvTile - 1) / fa::kKvTile;
-        if (items < persistent_grid() || items * tiles < ((flags & FA_FLAG_CAUSAL) ? 3 : 1) * kVarlenMinItemTiles)
+        if (items < persistent_grid() || items * tiles < ((flags & FA_FLAG_CAUSAL) ? 2 : 1) * kVarlenMinItemTiles)
             return false;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -683,15 +688,15 @@ int launch_varlen_long_and_short(const fa::FwdParams& base, int B, int H, hipStr
     int* items = count + 64;  // (256-byte aligned behind the count)
     p.varlen_count = count;
     p.varlen_items = items;
-    p.long_q = causal ? kVarlenLongCausalFull : kVarlenLongRows;
-    p.long_k = causal ? kVarlenLongCausal : kVarlenLongRows;
+    p.long_q = causal ? kVarlenLongCausalFull : fa::kVarlenByCost;
+    p.long_k = causal ? kVarlenLongCausal : fa::kVarlenByCost;
     p.q_blocks = (p.lq + 255) / 256;
     p.scale_log2e = 1.44269504088896340736f / std::sqrt((float)fa::kHeadDim);
     long grid = persistent_grid();
     if (grid > max_items) grid = max_items;
     hipLaunchKernelGGL(fa::fa_varlen_plan_kernel, dim3(1), dim3(256), 0, stream, base.q_len, base.k_len, B, H, base.lq,
                        base.lk, p.long_q, p.long_k, causal ? 1 : 0, (int)grid,
-                       switches().varlen_w64 < 0 ? (float)kVarlenMinItemTiles * 16384.0f : 0.0f, items, count);
+                       switches().varlen_w64 < 0 ? (float)kVarlenMinItemTilesPlanned * 16384.0f : 0.0f, items, count);
     if (causal)
         hipLaunchKernelGGL(fa::fa_fwd_w64_varlen_causal_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     else

@@ -150,8 +150,9 @@ int fa_forward_general(const uint16_t* dQ, const uint16_t* dK, const uint16_t* d
  * synchronisation); either may be NULL (= Lq, Lk for every sequence); values are clamped to [0, Lq] and [0, Lk]; a
  * sequence without keys gets O = 0.  With FA_FLAG_CAUSAL key j is visible to query i iff j <= i (both counted from
  * the sequence's start; Lq and Lk may differ).  D of 64, 128 or 256.
- *   At D = 128 the long sequences of a batch (without the mask at least 1100 query rows and keys; with it as many
- * rows as keys and at least 1665, or 2305 when the last 256-row block is at most half full) run on the default
+ *   At D = 128 the long sequences of a batch (without the mask those that cost less there by a model of both
+ * kernels, from about 640 rows and keys on; with it as many rows as keys and at least 1665, or 2305 when the last
+ * 256-row block is at most half full) run on the default
  * kernel's ragged forms from a device-built item list (16 bytes per head and 256-row block of the padded batch, from
  * the stream's memory pool, hipMallocAsync; not on a stream under capture), the other sequences after them on the
  * 128-row kernel, unless they hold so little of the work that they join the list; batches too small to fill the

@@ -632,14 +632,27 @@ def test_padded_batch_only_key_lengths_given(fa, oracle, dev):
 
 def _on_tuned_kernel(q_lens, k_lens, causal):
     """Which sequences of a padded D = 128 batch the library hands to the tuned kernel's list form (the rule of
-    fa_varlen_plan_kernel): those over the thresholds; and when the ones below them that the list form can take at
-    all hold at most a quarter of the batch's rows x keys, those as well."""
+    fa_varlen_plan_kernel and fa::varlen_on_tuned): without the mask those that cost less there, with it those over
+    the thresholds; and when the others that the list form can take at all hold at most a quarter of the batch's
+    rows x keys, those as well."""
     def over(ql, kl, tq, tk):
         if not causal:
-            return ql >= tq and kl >= tk
-        return ql == kl and ql >= (tq if (ql - 1) % 256 + 1 > 128 else tk)
+            if tq != -1:
+                return ql >= tq and kl >= tk
+            if ql < 64 or kl < 192:  # (by cost: 256-row items against 128-row workgroups, two to a compute unit)
+                return False
+            f32 = np.float32
+            tuned = f32(-(-ql // 256)) * (f32(1.33) * f32(-(-kl // 64)) + f32(3.6))
+            rows128 = f32(0.5) * f32(-(-ql // 128)) * (f32(0.8535) * f32(-(-kl // 32)) + f32(0.094))
+            return bool(tuned < rows128)
+        if ql != kl:
+            return False
+        last = (ql - 1) % 256 + 1
+        if tq == 1665 and last >= 192 and ql >= 960:
+            return True
+        return ql >= (tq if last > 128 else tk)
 
-    tq, tk = (1665, 2305) if causal else (1100, 1100)
+    tq, tk = (1665, 2305) if causal else (-1, -1)
     mq, mk = (192, 192) if causal else (64, 192)
     w_long = sum(float(a) * b for a, b in zip(q_lens, k_lens) if over(a, b, tq, tk))
     w_mid = sum(float(a) * b for a, b in zip(q_lens, k_lens) if not over(a, b, tq, tk) and over(a, b, mq, mk))
@@ -650,9 +663,10 @@ def _on_tuned_kernel(q_lens, k_lens, causal):
 
 @pytest.mark.parametrize("H", [9, 2])
 def test_padded_batch_long_and_short_sequences(fa, oracle, dev, H, fa_env):
-    """A padded batch at D = 128 whose lengths straddle the threshold (1100 query rows and keys) from which a
-    sequence runs on the tuned kernel's ragged form with its own lengths: both sides of it by one row, lengths that
-    are and are not whole tiles, a sequence long in rows and short in keys (and the other way round), an empty
+    """A padded batch at D = 128 with sequences on both sides of the rule by which a sequence runs on the tuned kernel's
+    ragged form with its own lengths (what it costs there against the 128-row kernel): lengths that are and are not
+    whole tiles, a sequence with few rows and many keys (300 x 1400: the 128-row kernel's), many rows and 1099 keys
+    (a tie that the 128-row kernel gets), an empty
     one, and 9 heads (groups of eight and one) / 2.  The two kernels write disjoint sequences; together the
     batch; same bits as the 128-row kernel alone on the sequences it keeps.  In the 2-head batch the one short
     sequence (64 rows) holds 2 % of the work and joins the list instead of costing a launch of its own."""
@@ -679,7 +693,7 @@ def test_padded_batch_long_and_short_sequences(fa, oracle, dev, H, fa_env):
     torch.cuda.synchronize()
     assert torch.equal(auto, one)  # (left to itself the library keeps a batch this small on the 128-row kernel)
     tuned = _on_tuned_kernel(q_lens, k_lens, False)
-    assert tuned == ([True, True, False, True, False, False, False, True] if H == 9 else [True] * 4)
+    assert tuned == ([True, False, True, True, False, False, False, True] if H == 9 else [True] * 4)
     for b in range(B):
         if not tuned[b]:
             assert torch.equal(both[b], one[b]), f"sequence {b}"
@@ -738,7 +752,7 @@ def test_padded_batch_of_more_sequences_than_the_planner_sorts(fa, oracle, dev, 
     Q, K, V = [rng.standard_normal((B, H, L, D), dtype=np.float32).astype(np.float16) for _ in range(3)]
     q, k, v = [torch.from_numpy(a).to(dev) for a in (Q, K, V)]
     ql = torch.tensor(lens, dtype=torch.int32, device=dev)
-    fa_env(FA_VARLEN_W64=None)
+    fa_env(FA_VARLEN_W64="1")  # (the batch is near the library's own limit for the route: not what this test is about)
     both = fa.attention_varlen(q, k, v, ql, ql)
     assert torch.equal(both, fa.attention_varlen(q, k, v, ql, ql))  # (fixed item lists: the same bits every time)
     both_causal = fa.attention_varlen(q, k, v, ql, ql, causal=True)
