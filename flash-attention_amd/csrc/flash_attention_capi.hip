@@ -575,12 +575,14 @@ int launch_hd_maybe_split(const fa::FwdParams& p, int D, HdRoute r, hipStream_t 
 // 2 % difference).  The tuned kernel runs whole rounds of 256-row items, one per compute unit, each costing its
 // tiles and 3.6 us of item boundary; the 128-row kernel runs two workgroups per unit with no rounds to speak of
 // and 14 us more of fixed cost.  So 511, 767 or 1023 rows in a batch that makes whole rounds are 13 % faster on
-// the tuned kernel, and 513 rows 13 % slower: a threshold on the length alone cannot say that.  Only where both
-// kernels fill the chip; elsewhere (and without the batch: bh = 0) the threshold stays.
+// the tuned kernel, and 513 rows 13 % slower: a threshold on the length alone cannot say that.  Only for batches of
+// two rounds or more; elsewhere (and without the batch: bh = 0) the threshold stays.
 bool ragged_w64_faster(long bh, int lq, int lk) {
     const long grid = persistent_grid(), cus = device_cus();
     const long items256 = bh * ((lq + 255) / 256), items128 = bh * ((lq + 127) / 128);
-    if (items256 < grid || items128 < 2 * cus) return lq >= 1100;
+    // (the models hold from two rounds on: with one or two, a round that is not full runs faster than a whole one and
+    // the 128-row kernel's fixed cost is smaller than fitted; tools/micro/ragged_rule.py --heads 5)
+    if (items256 < 2 * grid || items128 < 4 * cus) return lq >= 1100;
     const double rounds = (double)((items256 + grid - 1) / grid);
     const double t_w64 = 8.0 + rounds * (1.33 * ((lk + 63) / 64) + 3.6);
     const double t_hd = 22.4 + (double)items128 / (2.0 * cus) * (0.8535 * ((lk + 31) / 32) + 0.094);

@@ -2,7 +2,7 @@
 """Where the ragged tuned kernel beats the 128-row kernel on one unmasked sequence length, by the fill of the last
 256-row block: L = base + r for bases of whole blocks and r rows in the last one; FA_MASKED_W64=1 against 0
 (B*L ~ 16384, H = 16, pattern data, 0.4 s preheat per line).  The launcher's rule (masked_on_w64) is fitted to this.
-    python tools/micro/ragged_rule.py [--causal]"""
+    python tools/micro/ragged_rule.py [--causal] [--heads H]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -11,6 +11,8 @@ import __graft_entry__ as ge
 fa = ge.load_package()
 dev = torch.device("cuda:0")
 H, D = 16, 128
+if "--heads" in sys.argv:  # (fewer heads: batches of one to two rounds of 256-row items)
+    H = int(sys.argv[sys.argv.index("--heads") + 1])
 causal = "--causal" in sys.argv
 n = 16384 * H * D + 16384 * H * D
 buf = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(4)]
