@@ -33,6 +33,10 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   normal_data_tflops, reference_protocol_tflops
                 the timed shape on N(0,1) inputs (compare_impls.py:84-87), and with the reference driver's
                 own protocol (warm-up 3, five launches, one event pair each, no preheat; :148-215)
+  cold_inputs_tflops
+                the timed shape with its four tensors rotated through four independent sets, so that no read is
+                served from the 256 MiB last-level cache (the timed steps, like the reference driver's, launch
+                the same 4 x 64 MiB every time)
   clock_ghz_effective, clock_ghz_effective_normal_data
                 the shader clock under the kernel's own load on either data set (in-kernel s_memtime /
                 s_memrealtime stamps of the library's diagnostic twin): the two data sets run the same
@@ -599,6 +603,31 @@ def run_heads(args, fa, torch, ranks, dev):
                                   "twin (libflash_attention_stamps.so) under back-to-back launches of this shape"
                                   if cp else "diagnostic twin not built or shape not served")
         del qn, kn, vn
+        # The timed steps launch the same four tensors again and again (as the reference driver does,
+        # benchmark_tensor_flash_attention.cu:148-215); at 4 x 64 MiB they are as large as the chip's last-level
+        # cache, which then serves part of the input reads.  The same launches with Q, K, V and O rotated through
+        # four independent sets (1 GiB touched between two uses of a line: every read comes from HBM):
+        try:
+            sets = [(q, k, v, o)]
+            for s_ in range(1, 4):
+                extra = [torch.empty_like(q) for _ in range(4)]
+                for t, seed in zip(extra[:3], (1234, 2345, 3456)):
+                    fa.init_half(t, seed + 7 * s_)
+                sets.append(tuple(extra))
+            turn = [0]
+
+            def rotating():
+                qq, kk, vv, oo = sets[turn[0] & 3]
+                turn[0] += 1
+                fa.attention(qq, kk, vv, out=oo)
+
+            _, ms_c = time_steps(torch, rotating, max(8, args.steps // 2), 4, lambda: None,
+                                 min(args.preheat_seconds, 1.0))
+            result["cold_inputs_tflops"] = flops_local / (ms_c * 1e-3) / 1e12
+            del sets
+        except RuntimeError as e:  # not enough free memory for the extra sets
+            result["cold_inputs_tflops"] = None
+            result["cold_inputs_note"] = f"{type(e).__name__}: {str(e)[:120]}"
 
     if rank == 0 and world == 1 and not args.no_sweep:
         n_all = 16384 * H * D

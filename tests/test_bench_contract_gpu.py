@@ -35,6 +35,7 @@ def test_bench_json_line():
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert j["normal_data_tflops"] > 0 and j["reference_protocol_tflops"] > 0 and j["pct_of_fp16_peak"] > 0
+    assert "cold_inputs_tflops" in j and (j["cold_inputs_tflops"] is None or j["cold_inputs_tflops"] > 0)
     assert j["per_rank_kernel_ms"] == [rf["kernel_ms"]] and rf["key_split_ways"] == 1
     # provenance: where the traffic figure comes from, and the clock the kernel ran at on either data set
     assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
