@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "run_tensor_flash_attention_host_half",
     "fa_forward",
     "fa_forward_host_half",
+    "fa_forward_host_half_sharded",
     "fa_forward_noalloc",
     "fa_forward_block",
     "fa_forward_general",
@@ -87,6 +88,8 @@ def bind(path: str) -> ct.CDLL:
     for name in ("fa_forward", "fa_forward_host_half"):
         getattr(L, name).argtypes = sig
         getattr(L, name).restype = ct.c_int
+    L.fa_forward_host_half_sharded.argtypes = sig[:-2] + [ct.POINTER(ct.c_int), ct.c_int, FloatPtr]
+    L.fa_forward_host_half_sharded.restype = ct.c_int
     L.fa_forward_noalloc.argtypes = sig[:-1]
     L.fa_forward_noalloc.restype = ct.c_int
     L.fa_forward_block.argtypes = (
@@ -181,6 +184,37 @@ def attention_host_half(Q: np.ndarray, K: np.ndarray, V: np.ndarray, tile: int =
     )
     _check(rc)
     return O, float(ms.value)
+
+
+def attention_host_half_sharded(Q: np.ndarray, K: np.ndarray, V: np.ndarray, devices=None, tile: int = 64):
+    """The host-pointer path over several GPUs of this node from one process (``fa_forward_host_half_sharded``):
+    the flattened B*H axis in contiguous ranges, one per entry of ``devices`` (a list of GPU indices, an int n for
+    GPUs 0..n-1, or None for every visible GPU).  Returns (fp16 O, [kernel-only ms of each range])."""
+    B, H, L, D = Q.shape
+    if K.shape != Q.shape or V.shape != Q.shape:
+        raise ValueError("Q, K, V must share one [B,H,L,D] shape")
+    O = np.empty_like(Q)
+    if devices is None:
+        dev_arr, n = None, 0
+        n_out = max(1, device_count())
+    elif isinstance(devices, int):
+        dev_arr, n = None, devices
+        n_out = max(1, devices)
+    else:
+        n = n_out = len(devices)
+        dev_arr = (ct.c_int * max(1, n))(*devices)
+    ms = (ct.c_float * n_out)()
+    rc = lib().fa_forward_host_half_sharded(
+        _np_half_ptr(Q), _np_half_ptr(K), _np_half_ptr(V), _np_half_ptr(O), B, H, L, D, tile, dev_arr, n, ms)
+    _check(rc)
+    return O, [float(x) for x in ms]
+
+
+def device_count() -> int:
+    """GPUs visible to this process (asks torch, which this front end maps first)."""
+    import torch
+
+    return torch.cuda.device_count()
 
 
 def attention(q, k, v, out=None, tile: int = 64, stream=None, timed: bool = False):

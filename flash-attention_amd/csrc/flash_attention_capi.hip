@@ -14,6 +14,8 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "fa_fwd_kernel.hpp"
 #ifdef FA_AB_KERNELS
@@ -1026,6 +1028,77 @@ int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t*
                               [&](uint16_t* const* d) -> int {
                                   return fa_forward(d[0], d[1], d[2], d[3], B, H, L, D, tile, stream_, elapsed_ms);
                               });
+}
+
+// One process, several GPUs, host pointers: the flattened B*H axis is cut into contiguous ranges (the first
+// B*H % n ranges one head longer: multi_gpu.head_shard's rule), one per entry of `devices`, and one host thread per
+// range does what the single-device entry point does for the whole tensor (allocate, copy in, launch, copy out,
+// free) on its device and a stream of its own.  A head is one contiguous L*D slab of every tensor, so a range is
+// one contiguous piece of each host buffer, and the ranges share nothing: no collective, no peer access.
+int fa_forward_host_half_sharded(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                                 int H, int L, int D, int tile, const int* devices, int n_devices,
+                                 float* elapsed_ms_per_device) {
+    g_last_error[0] = 0;
+    if (int rc = validate(B, H, L, D, tile)) return rc;
+    if (!hQ || !hK || !hV || !hO) return fail(FA_ERR_POINTER, "fa_forward_host_half_sharded: null pointer%s");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        (void)hipGetLastError();
+        return fail(FA_ERR_RUNTIME, "fa_forward_host_half_sharded: no GPU visible%s");
+    }
+    if (n_devices <= 0) {
+        if (devices) return fail(FA_ERR_SHAPE, "fa_forward_host_half_sharded: a device list needs n_devices > 0%s");
+        n_devices = visible;
+    }
+    if (n_devices > 4096) return fail(FA_ERR_SHAPE, "fa_forward_host_half_sharded: more than 4096 ranges%s");
+    std::vector<int> dev(n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        dev[i] = devices ? devices[i] : i;
+        if (dev[i] < 0 || dev[i] >= visible) {
+            std::snprintf(g_last_error, sizeof(g_last_error),
+                          "fa_forward_host_half_sharded: device %d (entry %d) is not one of the %d visible GPUs", dev[i], i,
+                          visible);
+            return FA_ERR_SHAPE;
+        }
+    }
+    const int heads = B * H, base = heads / n_devices, extra = heads % n_devices;
+    const size_t head_elems = (size_t)L * D;
+    std::vector<int> rcs(n_devices, FA_OK);
+    std::vector<float> ms(n_devices, 0.0f);
+    std::vector<std::string> errs(n_devices);
+    std::vector<std::thread> workers;
+    for (int i = 0; i < n_devices; ++i) {
+        const int first = i * base + (i < extra ? i : extra), count = base + (i < extra ? 1 : 0);
+        if (count == 0) continue;  // more ranges than heads: the last ones have nothing to do
+        workers.emplace_back([&, i, first, count] {
+            auto failed = [&](int rc, const char* what, hipError_t e) {
+                rcs[i] = rc;
+                errs[i] = std::string("device ") + std::to_string(dev[i]) + ": " + what + ": " + hipGetErrorString(e);
+            };
+            hipError_t e = hipSetDevice(dev[i]);
+            if (e != hipSuccess) return failed(FA_ERR_RUNTIME, "hipSetDevice", e);
+            hipStream_t stream = nullptr;
+            e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return failed(FA_ERR_RUNTIME, "hipStreamCreate", e);
+            const size_t off = (size_t)first * head_elems, bytes = (size_t)count * head_elems * sizeof(uint16_t);
+            rcs[i] = with_device_copies(hQ + off, hK + off, hV + off, hO + off, bytes, bytes, stream,
+                                        "fa_forward_host_half_sharded", [&](uint16_t* const* d) -> int {
+                                            return fa_forward(d[0], d[1], d[2], d[3], 1, count, L, D, tile, stream,
+                                                              elapsed_ms_per_device ? &ms[i] : nullptr);
+                                        });
+            if (rcs[i] != FA_OK) errs[i] = std::string("device ") + std::to_string(dev[i]) + ": " + g_last_error;
+            (void)hipStreamDestroy(stream);
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    if (elapsed_ms_per_device)
+        for (int i = 0; i < n_devices; ++i) elapsed_ms_per_device[i] = ms[i];
+    for (int i = 0; i < n_devices; ++i)
+        if (rcs[i] != FA_OK) {
+            std::snprintf(g_last_error, sizeof(g_last_error), "fa_forward_host_half_sharded: %s", errs[i].c_str());
+            return rcs[i];
+        }
+    return FA_OK;
 }
 
 int fa_forward_general_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,

@@ -77,7 +77,7 @@ enum {
  * Launches with fewer (head, 256-row query block) items than TWICE the resident workgroups (one per compute unit,
  * less fa_set_reserved_cus) may divide every head's keys into ranges when a cost model says it pays
  * (fa_split_ways() is the authority; typically few heads and a long sequence, e.g. one rank's two heads of B=1,
- * H=16, L=16384 sharded over eight GPUs: 128 items on 256 units): they run the ranges as heads of their own and fold them with a run the ranges as heads of their own and fold them with a
+ * H=16, L=16384 sharded over eight GPUs: 128 items on 256 units): they run the ranges as heads of their own and fold them with a
  * second, small kernel.  The reference never meets this: its grid is (L/64, B, H) workgroups of 64 rows
  * (wrapper.cu:74-76).  The workspace (520 bytes per query row and range) is taken from the stream's memory pool
  * (hipMallocAsync / hipFreeAsync: stream-ordered, no device synchronisation) and returned to it by the same call;
@@ -87,6 +87,23 @@ int fa_forward(const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint1
                int D, int tile, void* stream, float* elapsed_ms);
 int fa_forward_host_half(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
                          int H, int L, int D, int tile, void* stream, float* elapsed_ms);
+
+/* The host-pointer entry point over several GPUs of one node, from ONE process.  No counterpart in the reference
+ * (README.md:47 lists multi-GPU as future work); the partition follows from its kernel's grid, whose (batch, head)
+ * axes are independent (tensor_flash_attention.cu:30-31): the flattened B*H axis is cut into n_devices contiguous
+ * ranges (the first B*H % n_devices of them one head longer), range i runs on GPU devices[i] (devices == NULL:
+ * GPU i; n_devices <= 0 with devices == NULL: every visible GPU).  Each range is one contiguous piece of the four
+ * host buffers and is handled by a host thread of its own exactly as fa_forward_host_half handles the whole
+ * tensor (device buffers, copy in, kernel, copy out, free, on a stream of its own), so the copies of different
+ * GPUs run side by side on their own links and nothing is exchanged between GPUs.  A GPU may be named more than
+ * once (its ranges then share the device); ranges without a head (n_devices > B*H) do nothing.
+ * elapsed_ms_per_device: NULL, or n_devices floats that receive each range's kernel-only milliseconds (0 for an
+ * empty range); total FLOPs over their maximum is the aggregate rate.  Returns after every range has finished;
+ * the first failing range's status is returned and its message (with the device) is in fa_last_error().  The
+ * caller's current device is left as it was. */
+int fa_forward_host_half_sharded(const uint16_t* hQ, const uint16_t* hK, const uint16_t* hV, uint16_t* hO, int B,
+                                 int H, int L, int D, int tile, const int* devices, int n_devices,
+                                 float* elapsed_ms_per_device);
 
 /* fa_forward for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
  * harnesses that forbid it.  No counterpart in the reference.  Same arguments, result and kernels as fa_forward

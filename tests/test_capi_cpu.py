@@ -126,3 +126,17 @@ def test_varlen_and_noalloc_validation(fa):
     assert L.fa_forward_noalloc(p, p, p, p, 1, 1, 100, 128, 64, None) == 2
     assert L.fa_forward_noalloc(p, p, p, None, 1, 1, 64, 128, 64, None) == 5
     assert L.fa_set_reserved_cus(-1) == 4
+
+
+def test_sharded_host_entry_point_validation(fa):
+    """Shape and pointer errors of the several-GPU host entry point come before any device work; on a machine
+    without a GPU a well-formed call reports that (and does not crash)."""
+    import torch
+
+    L = fa.lib()
+    buf = np.zeros(64 * 128, dtype=np.float16)
+    p = buf.ctypes.data_as(fa.HalfPtr)
+    sh = lambda B=1, H=1, Ls=64, D=128, tile=64, o=p: L.fa_forward_host_half_sharded(p, p, p, o, B, H, Ls, D, tile, None, 1, None)
+    assert sh(tile=32) == 1 and sh(Ls=100) == 2 and sh(D=64) == 3 and sh(B=0) == 4 and sh(o=None) == 5
+    if not torch.cuda.is_available():
+        assert sh() == 6 and b"no GPU visible" in L.fa_last_error()
