@@ -55,7 +55,11 @@ constexpr int kRowsPerWave = 32;  // query rows owned by one wave
 constexpr int kRowBytes = kHeadDim * 2;
 constexpr int kTileBytes = kKvTile * kRowBytes;  // 16 KiB
 constexpr int kLdsBytes = 4 * kTileBytes;        // K and V, two buffers each (the per-wave staging images follow)
-constexpr float kRescaleSlack = 8.0f;            // log2 units a row max may run ahead of its reference
+constexpr float kRescaleSlack = 8.0f;
+// Cache-policy bits of the output rows' global stores (store_staged_rows; see there).
+#ifndef FA_STORE_MODS
+#define FA_STORE_MODS "sc1 nt"
+#endif            // log2 units a row max may run ahead of its reference
 
 enum : int {
     kFlagLoadState = 1,   // start from (o_acc, row_max, row_sum) instead of zero
@@ -466,11 +470,21 @@ __device__ __forceinline__ void store_staged_rows(half_t* o_rows, const char* im
 #ifdef FA_ABLATE_NO_STORE
         asm volatile("" ::"v"(v[i]));
 #else
-        // streaming store: a plain store leaves the output dirty in the L2 (32 MiB across the chip, half of
-        // a 64 MiB output), and the write-back at the end of the kernel then delays the next launch
-        // (measured at L=512: 6.7 us between consecutive launches, 4.6 us with these)
-        if (first_row <= 0 || 4 * i + row0 >= first_row)
-            __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(wr + i * 4 * kHeadDim));
+        // Device-scope, non-temporal store ("sc1 nt"): the rows go through the XCD's L2 to memory as they are
+        // written.  A plain store leaves the output dirty in the L2 (32 MiB across the chip, half of a 64 MiB
+        // output), and the write-back at the end of the kernel then delays the next launch: measured at L = 512,
+        // 6.7 us between consecutive launches, 4.6 us with the non-temporal hint alone (lines marked for early
+        // eviction, still written back), and a little less again with the device scope on top (tools/ab.py, one
+        // process, four boxes: 65.3 -> 63.4, 63.2 -> 62.0, 62.9 -> 62.5 and 62.2 -> 61.9 us per launch, i.e. 0.5 - 3 %;
+        // "sc1", "sc0 sc1" and "sc0 sc1 nt" within 0.5 us of it, plain stores 67.2; nothing measurable from
+        // L = 1024 on or on N(0,1) data; same bits).  -DFA_STORE_MODS="..." builds another policy for comparison.
+        if (first_row <= 0 || 4 * i + row0 >= first_row) {
+            const half_t* base_ = wr + (i >> 2) * 16 * kHeadDim;
+            if ((i & 3) == 0) asm volatile("global_store_dwordx4 %0, %1, off " FA_STORE_MODS : : "v"(base_), "v"(v[i]) : "memory");
+            if ((i & 3) == 1) asm volatile("global_store_dwordx4 %0, %1, off offset:1024 " FA_STORE_MODS : : "v"(base_), "v"(v[i]) : "memory");
+            if ((i & 3) == 2) asm volatile("global_store_dwordx4 %0, %1, off offset:2048 " FA_STORE_MODS : : "v"(base_), "v"(v[i]) : "memory");
+            if ((i & 3) == 3) asm volatile("global_store_dwordx4 %0, %1, off offset:3072 " FA_STORE_MODS : : "v"(base_), "v"(v[i]) : "memory");
+        }
 #endif
     }
 }

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--data", default="pattern")
 ap.add_argument("--preheat", type=float, default=1.0)
+ap.add_argument("--libs", nargs="*", default=[], help="experiment builds to time instead of the product (B = 32 only)")
 args = ap.parse_args()
 fa = ge.load_package()
 dev = torch.device("cuda:0")
@@ -69,6 +70,17 @@ def run(B, nsets, only_out_rotates=False):
     torch.cuda.empty_cache()
 
 
+if args.libs:  # same buffers against rotated ones, per build (timing builds may give wrong results: only times count)
+    for rep in range(2):
+        for path in ["product"] + args.libs:
+            if path != "product":
+                fa._lib = fa.bind(os.path.join(ROOT, path))
+            print(path, end=": ")
+            run(32, 1)
+            print(path, end=": ")
+            run(32, 4)
+            fa._lib = None
+    sys.exit(0)
 for rep in range(2):
     run(32, 1)
     run(32, 4)
