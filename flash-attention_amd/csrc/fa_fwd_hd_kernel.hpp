@@ -707,7 +707,10 @@ __device__ __forceinline__ void fa_fwd_hd_body(const FwdParams& p) {
 #ifdef FA_HD_ABLATE_STORE  // (timing experiments only: wrong results)
                 asm volatile("" ::"v"(v[i]));
 #else
-                if (row < n_rows) __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(og + (size_t)row * D));
+                if (row < n_rows) {  // (device scope + non-temporal, as in fa::store_staged_rows)
+                    const half_t* a_ = og + (size_t)row * D;
+                    asm volatile("global_store_dwordx4 %0, %1, off " FA_STORE_MODS : : "v"(a_), "v"(v[i]) : "memory");
+                }
 #endif
             }
         });
