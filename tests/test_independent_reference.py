@@ -126,3 +126,51 @@ def test_padded_batch_against_pytorch_per_sequence(fa, oracle, causal):
         ref = sdpa_fp32(Q[b:b + 1, :, :n], K[b:b + 1, :, :n], V[b:b + 1, :, :n], causal, device=dev)
         m = oracle.error_metrics(ref, got[b:b + 1, :, :n])
         assert m["max_abs"] <= MAX_ABS_TOL and m["global_rel"] <= REL_L2_TOL, (b, n, m)
+
+
+# ------------------------------------------------------------------------------------------------
+# Properties that hold at any size: checked at the benchmark's full shapes, where the CPU oracle only reaches
+# slices.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(32, 512), (1, 16384)])
+def test_keys_may_come_in_any_order(fa, B, L):
+    """softmax(Q K^T) V does not depend on the order of the (key, value) pairs: the same permutation applied to the
+    rows of K and V of every head changes the order of summation only."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    q, k, v = [torch.randn((B, 16, L, 128), generator=g, device=dev, dtype=torch.float32).to(torch.float16) for _ in range(3)]
+    perm = torch.randperm(L, generator=g, device=dev)
+    o1 = fa.attention(q, k, v)
+    o2 = fa.attention(q, k[:, :, perm].contiguous(), v[:, :, perm].contiguous())
+    torch.cuda.synchronize()
+    d = (o1.float() - o2.float()).abs()
+    # two fp16 roundings of nearly the same fp32 value: an ulp of the output at most, far inside the parity gate
+    assert d.max().item() <= 2e-3 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(8, 2048), (1, 16384)])
+def test_causal_rows_do_not_see_later_keys(fa, B, L):
+    """With the mask of testing.cu:74-77 a query row's output is a function of the keys up to its own position:
+    overwriting every later key and value with large values leaves those rows as they were.  (Finite
+    values: a masked key's weight is exactly 0, and 0 x NaN is NaN in attention_cpu's P.V loop as well,
+    testing.cu:114-122.)"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(6)
+    q, k, v = [torch.randn((B, 16, L, 128), generator=g, device=dev, dtype=torch.float32).to(torch.float16) for _ in range(3)]
+    o1 = fa.attention_general(q, k, v, causal=True)
+    for cut in (1, 63, 64, L // 2 + 17, L - 1):
+        k2, v2 = k.clone(), v.clone()
+        k2[:, :, cut:] = 30.0
+        v2[:, :, cut:] = 1000.0
+        o2 = fa.attention_general(q, k2, v2, causal=True)
+        torch.cuda.synchronize()
+        # Bit for bit up to the last 32-row sub-block that lies wholly before the cut.  Rows that share a sub-block
+        # with rows behind the cut keep their values within an fp16 ulp: the kernel moves a row's reference point
+        # (the deferred rescale) together with its sub-block's, and P is rounded to fp16 relative to it.
+        whole = cut // 32 * 32
+        assert torch.equal(o1[:, :, :whole], o2[:, :, :whole]), cut
+        d = (o1[:, :, whole:cut].float() - o2[:, :, whole:cut].float()).abs()
+        assert d.numel() == 0 or d.max().item() <= 4e-3, (cut, d.max().item())
+        assert torch.isfinite(o2[:, :, :cut].float()).all()
