@@ -475,7 +475,8 @@ __device__ __forceinline__ void store_staged_rows(half_t* o_rows, const char* im
         // output), and the write-back at the end of the kernel then delays the next launch: measured at L = 512,
         // 6.7 us between consecutive launches, 4.6 us with the non-temporal hint alone (lines marked for early
         // eviction, still written back), and a little less again with the device scope on top (tools/ab.py, one
-        // process, four boxes: 65.3 -> 63.4, 63.2 -> 62.0, 62.9 -> 62.5 and 62.2 -> 61.9 us per launch, i.e. 0.5 - 3 %;
+        // process, four boxes: 65.3 -> 63.4, 63.2 -> 62.0, 62.9 -> 62.5 and 62.2 -> 61.9 us per launch, i.e. 0.5 - 3 %; on one
+        // time axis the time between two launches falls from 4.5 to 4.1 us and the rest is inside the spread;
         // "sc1", "sc0 sc1" and "sc0 sc1 nt" within 0.5 us of it, plain stores 67.2; nothing measurable from
         // L = 1024 on or on N(0,1) data; same bits).  -DFA_STORE_MODS="..." builds another policy for comparison.
         if (first_row <= 0 || 4 * i + row0 >= first_row) {
