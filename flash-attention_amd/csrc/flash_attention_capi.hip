@@ -1070,7 +1070,7 @@ int fa_forward_host_half_sharded(const uint16_t* hQ, const uint16_t* hK, const u
     for (int i = 0; i < n_devices; ++i) {
         const int first = i * base + (i < extra ? i : extra), count = base + (i < extra ? 1 : 0);
         if (count == 0) continue;  // more ranges than heads: the last ones have nothing to do
-        workers.emplace_back([&, i, first, count] {
+        auto work = [&, i, first, count] {
             auto failed = [&](int rc, const char* what, hipError_t e) {
                 rcs[i] = rc;
                 errs[i] = std::string("device ") + std::to_string(dev[i]) + ": " + what + ": " + hipGetErrorString(e);
@@ -1088,7 +1088,14 @@ int fa_forward_host_half_sharded(const uint16_t* hQ, const uint16_t* hK, const u
                                         });
             if (rcs[i] != FA_OK) errs[i] = std::string("device ") + std::to_string(dev[i]) + ": " + g_last_error;
             (void)hipStreamDestroy(stream);
-        });
+        };
+        try {
+            workers.emplace_back(work);
+        } catch (const std::exception& e) {  // no thread to be had: this range reports it, the started ones finish
+            rcs[i] = FA_ERR_RUNTIME;
+            errs[i] = std::string("device ") + std::to_string(dev[i]) + ": could not start a host thread: " + e.what();
+            break;
+        }
     }
     for (std::thread& t : workers) t.join();
     if (elapsed_ms_per_device)
